@@ -1,0 +1,231 @@
+/*
+ * mm_engine.h — C ABI of the MI355X-native matchmaking search engine.
+ *
+ * This is the drop-in boundary for ONE path of OpenMatchmaking/microservice-matchmaking:
+ * the search/seed loop of `Matchmaking.Search.Worker` plus the external
+ * `strategist.match.check` predicate it calls.  The reference has no FFI of its own
+ * (it is 100 % Elixir); these are the entry points an Erlang dirty NIF would bind
+ * (see INTEGRATION.md for the NIF stub and the Elixir module that replaces
+ * `Search.Worker.consume/5`).  Every export cites the reference code it replaces;
+ * paths are relative to /root/reference/matchmaking/.
+ *
+ * Rules that hold for every function:
+ *   - plain C types only, no torch/HIP types in signatures;
+ *   - returns 0 (MM_OK) or a negative mm_status; never throws, aborts or exits
+ *     (a NIF crash would take the whole BEAM down — contrast the per-worker
+ *     `restart: :transient` isolation at lib/application.ex:8-14);
+ *   - one owner thread per engine, no internal locking (one GenServer owns one
+ *     engine, as one Search.Worker owns one channel: lib/search/worker.ex:220-237);
+ *   - distinct engines are independent (own HIP stream, own device memory).
+ *
+ * The library has exactly one backend: hand-written HIP kernels for gfx950.
+ * There is no CPU fallback; mm_engine_create() fails with MM_ERR_NO_DEVICE when no
+ * GPU is usable.  The CPU restatement used for parity testing lives in oracle/ and is
+ * never linked into this library.
+ */
+#ifndef MM_ENGINE_H
+#define MM_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1u
+
+#define MM_MAX_GROUPS 16u /* rating groups (reference ships 7: config/config.exs:27-36) */
+#define MM_MAX_MODES  16u /* game modes (4 bits in `cons`)                              */
+#define MM_MAX_ROLES  8u
+#define MM_MAX_TEAMS  4u
+#define MM_MAX_LOBBY  16u /* teams * team_size                                          */
+
+/* ---- player constraint word (`cons`), one u32 per queued player -------------------
+ * Restates the JSON fields of the player map the reference forwards untouched
+ * (lib/search/worker.ex:292-300) as a bit-packed SoA column.  Bits above 19 must be 0. */
+#define MM_CONS_MODE(c)   ((uint32_t)(c) & 0xFu)          /* "game-mode" (worker.ex:294)  */
+#define MM_CONS_REGION(c) (((uint32_t)(c) >> 4) & 0xFFu)  /* region id                    */
+#define MM_CONS_PARTY(c)  (((uint32_t)(c) >> 12) & 0xFu)  /* party size                   */
+#define MM_CONS_ROLE(c)   (((uint32_t)(c) >> 16) & 0xFu)  /* role id                      */
+#define MM_CONS_MAKE(mode, region, party, role)                                          \
+    (((uint32_t)(mode) & 0xFu) | (((uint32_t)(region) & 0xFFu) << 4) |                  \
+     (((uint32_t)(party) & 0xFu) << 12) | (((uint32_t)(role) & 0xFu) << 16))
+#define MM_CONS_USER_MASK 0x000FFFFFu
+
+/* mm_mode_config.flags */
+#define MM_MODE_REGION_FILTER 1u /* new.region must equal anchor.region */
+#define MM_MODE_PARTY_FILTER  2u /* new.party  must equal anchor.party  */
+
+/* mm_config.flags */
+#define MM_CFG_TIMING 1u /* record HIP-event timings of every kernel phase in mm_stats */
+
+typedef enum mm_status {
+    MM_OK = 0,
+    MM_ERR_INVALID_ARG = -1,  /* NULL pointer, bad mode/group/role index, bad config    */
+    MM_ERR_NO_DEVICE = -2,    /* no usable HIP device / library built without kernels   */
+    MM_ERR_OOM = -3,          /* device or pinned-host allocation failed                */
+    MM_ERR_FULL = -4,         /* pool capacity exhausted (slot ring has no free range)  */
+    MM_ERR_HIP = -5,          /* a HIP runtime call failed; mm_last_hip_error() has it  */
+    MM_ERR_INTERNAL = -6,     /* device-side invariant violated (reported, never abort) */
+    MM_ERR_ABI = -7,          /* cfg->abi_version != MM_ABI_VERSION                     */
+    MM_ERR_RANGE = -8         /* first/count outside the last tick's match list         */
+} mm_status;
+
+/* Inclusive integer rating range — one row of `config :matchmaking, RatingGroups`
+ * (config/config.exs:27-36). */
+typedef struct mm_rating_group {
+    int32_t from;
+    int32_t to;
+} mm_rating_group;
+
+/* Per-game-mode parameters of the match-check predicate (docs/MATCH_CHECK.md).  This is
+ * the state the external strategist (`strategist.match.check`, call site
+ * lib/search/worker.ex:296-306) would hold for a mode. */
+typedef struct mm_mode_config {
+    uint32_t team_size;               /* players per team, 1..8                         */
+    uint32_t teams;                   /* 2..MM_MAX_TEAMS                                */
+    uint32_t window;                  /* accept iff |r_new - r_anchor| <= window        */
+    uint32_t flags;                   /* MM_MODE_*                                      */
+    uint32_t n_roles;                 /* 1..MM_MAX_ROLES                                */
+    uint8_t  role_quota[MM_MAX_ROLES];/* seats per role per team; sums to team_size     */
+} mm_mode_config;
+
+typedef struct mm_config {
+    uint32_t abi_version;             /* MM_ABI_VERSION                                 */
+    uint32_t n_groups;                /* 1..MM_MAX_GROUPS                               */
+    mm_rating_group groups[MM_MAX_GROUPS];
+    uint32_t default_group;           /* index used when no range contains the rating
+                                         (generic/worker.ex:27: Enum.at(groups, div(n,2)+1)) */
+    uint32_t n_modes;                 /* 1..MM_MAX_MODES                                */
+    mm_mode_config modes[MM_MAX_MODES];
+    uint32_t capacity;                /* max simultaneously queued players (slot ring)  */
+    int32_t  device;                  /* HIP device ordinal                             */
+    uint32_t flags;                   /* MM_CFG_*                                       */
+} mm_config;
+
+/* Per-tick counters (SURVEY.md §5 "metrics": returned through the ABI because the
+ * reference only exposes queue depth via AMQP.Queue.status, search/worker.ex:326-334). */
+typedef struct mm_stats {
+    uint32_t pool_before;     /* queued players of this mode before the tick             */
+    uint32_t pool_after;      /* still queued after (includes players seated in lobbies) */
+    uint32_t matches;         /* lobbies emitted                                         */
+    uint32_t players_matched; /* matches * teams * team_size                             */
+    uint32_t passes_max;      /* max full queue rotations over the rating groups         */
+    uint32_t chains;          /* independent (group, mode) chains walked                 */
+    uint64_t pairs;           /* candidate-pair evaluations = match_check calls against a
+                                 non-empty lobby (the unit of SURVEY.md §8(d))           */
+    uint64_t scanned;         /* queue elements streamed, summed over passes             */
+    float    walk_ms;         /* HIP-event time of the walk kernel (MM_CFG_TIMING)       */
+    float    filter_ms;       /* HIP-event time of the liveness filter, 0 if not run     */
+    float    copy_ms;         /* D2H of counters + match list                            */
+    float    total_ms;        /* host wall time of mm_tick                               */
+} mm_stats;
+
+/* Timings of the last mm_enqueue*/
+typedef struct mm_enqueue_stats {
+    uint32_t accepted;        /* players placed into a (group, mode) queue               */
+    uint32_t rejected;        /* bad mode / role: dropped, slot left unused              */
+    float    bucket_ms;       /* HIP-event time of count+scan+scatter (MM_CFG_TIMING)    */
+    float    total_ms;
+} mm_enqueue_stats;
+
+typedef struct mm_engine mm_engine; /* opaque; NIF resource payload */
+
+/* ---- library-level -------------------------------------------------------------- */
+
+uint32_t    mm_abi_version(void);
+const char* mm_strerror(int status);
+
+/* Fills *cfg with the reference's shipped configuration: the 7 rating groups of
+ * config/config.exs:27-36, default_group = 4 ("diamond", generic/worker.ex:27), and one
+ * mode (index 0) = 1v1, window 50, no filters.  capacity = 1<<20, device 0. */
+int mm_config_default(mm_config* cfg);
+
+/* Replaces Matchmaking.Generic.Worker.find_rating_group_by_rating/1
+ * (lib/generic/worker.ex:46-53): first group, in table order, whose inclusive range
+ * contains `rating`; cfg->default_group otherwise (also for NaN, the stand-in for a
+ * non-number JSON value, which fails every `<=` under Erlang term order).  Pure host
+ * function; the device bucketing kernel applies the same rule to int32 ratings. */
+int mm_find_rating_group(const mm_config* cfg, double rating, uint32_t* group);
+
+/* ---- engine lifetime ------------------------------------------------------------- */
+
+/* Replaces Search.Worker.init/1 (lib/search/worker.ex:220-237) + LobbyState.init_store/0
+ * (lib/models/lobby_state.ex:15-29): one queue and one open-lobby record per
+ * (rating group, game mode), all device-resident.  Fails fast (like `{:error, :noconn}`,
+ * worker.ex:225-228) instead of degrading. */
+int  mm_engine_create(const mm_config* cfg, mm_engine** out);
+void mm_engine_destroy(mm_engine* e); /* NULL-safe; NIF resource destructor */
+
+/* Drops every queued player and open lobby (a fresh Mnesia + empty broker queues). */
+int mm_reset(mm_engine* e);
+
+/* ---- ingest ---------------------------------------------------------------------- */
+
+/* Replaces the delivery side of Search.Worker (handle_info(:basic_deliver),
+ * lib/search/worker.ex:352-358) together with the upstream bucketing hop
+ * Generic.Worker.consume/4 (lib/generic/worker.ex:55-69) and ActiveUser.add_user/1
+ * (lib/models/active_user.ex:46-55): appends n players, in array order, to the tails of
+ * their (group, mode) queues.  Array order == FIFO order == `seq`.
+ *   rating[i]  integer rating; cons[i] per MM_CONS_*; group[i] optional override of the
+ *   rating group (NULL = derive from rating by mm_find_rating_group; the override exists for
+ *   non-integer / missing ratings, which the host routes by A1 on the exact value).
+ *   out_slot[i] receives the engine handle of player i (stable until it is matched or
+ *   cancelled), or 0xFFFFFFFF if the player was rejected (mode not configured, role not
+ *   seatable).  Host pointers; the engine copies before returning. */
+int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const uint32_t* cons,
+               const uint8_t* group, uint32_t* out_slot, mm_enqueue_stats* st);
+
+/* Same, with rating/cons already resident in device memory (the benchmark path, and a
+ * GPU-side codec's hand-off).  Slots are first_slot + i (mod capacity). */
+int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rating,
+                      const uint32_t* d_cons, uint32_t* first_slot, mm_enqueue_stats* st);
+
+/* Replaces ActiveUser.remove_user/1 (lib/models/active_user.ex:57-66) as observed by the
+ * search loop through ActiveUser.in_queue?/1 (active_user.ex:33-44; uses at
+ * search/worker.ex:308 and :272): the players stop being "in queue".  Takes effect at
+ * the start of the next tick: queued ones vanish when popped, seated ones are filtered
+ * out of their open lobby (remove_inactive_players/1, search/worker.ex:267-280).
+ * Unknown / already matched slots are ignored. */
+int mm_cancel(mm_engine* e, uint32_t n, const uint32_t* slot);
+
+/* ---- search ---------------------------------------------------------------------- */
+
+/* Replaces Search.Worker.consume/5 (lib/search/worker.ex:291-324) run to quiescence under
+ * the canonical schedule of SURVEY.md §3.4 ("Mode R"), for every rating group of `mode`:
+ * FIFO first-fit seeding of the single open lobby per (group, mode)
+ * (LobbyState.get_state/update_state, lib/models/lobby_state.ex:61-131), rejected players
+ * to the tail (requeue_player/5, worker.ex:239-248 -> lib/requeue/worker.ex:51-54),
+ * lobby emission in publish order (worker.ex:313-319).  Blocks until the device is done
+ * (dirty-NIF: ERL_NIF_DIRTY_JOB_CPU_BOUND).  *n_matches = lobbies emitted; they stay
+ * readable through mm_matches() until the next mm_tick/mm_reset on this engine. */
+int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats);
+
+/* Copies matches [first, first+count) of the last tick, in emission order (rating group
+ * major — groups are independent workers in the reference, lib/application.ex:26-40 —
+ * then publish order within the group).  Per match: L = teams*team_size slots in team
+ * order ("team 1" players in seating order, then "team 2", ... — the `"teams"` map of
+ * worker.ex:315-318), score = |sum(team max) - sum(team min)| / team_size as f32 (for 1v1:
+ * |r1 - r2|), the rating group index, and the pass (queue rotation) it was emitted in.
+ * Any output pointer may be NULL. */
+int mm_matches(mm_engine* e, uint32_t first, uint32_t count, uint32_t* slots, float* score,
+               uint32_t* group, uint32_t* pass);
+
+/* Replaces Search.Worker.status/0 (lib/search/worker.ex:115-117, :326-334 ->
+ * AMQP.Queue.status message_count): per-group queue length for `mode`, not counting
+ * players seated in the open lobby. per_group has cfg.n_groups entries. */
+int mm_queue_depth(mm_engine* e, uint32_t mode, uint32_t* per_group);
+
+/* The open lobby of (mode, group) — the record LobbyState.get_state/4 would pop
+ * (lib/models/lobby_state.ex:61-104).  Writes up to MM_MAX_LOBBY (slot, team) pairs in
+ * team order; *n = seated players. */
+int mm_lobby_state(mm_engine* e, uint32_t mode, uint32_t group, uint32_t* n,
+                   uint32_t* slots, uint8_t* teams);
+
+/* Last HIP error code seen by this engine (0 if none) — for logs, never for control flow. */
+int mm_last_hip_error(const mm_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM_ENGINE_H */

@@ -1,0 +1,238 @@
+"""ctypes mirror of include/mm_engine.h and a thin object wrapper over it.
+
+`bind(lib, prefix)` types every export; `EngineBase` drives any library that exports the
+ABI under a prefix.  The product (`engine.Engine`) binds libmm_engine.so with prefix
+``mm_``; the test-only oracle binds its own library with ``mo_`` — the two are driven by
+identical calls, which is what makes the parity tests read like one test run twice.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+MM_ABI_VERSION = 1
+MM_MAX_GROUPS = 16
+MM_MAX_MODES = 16
+MM_MAX_ROLES = 8
+MM_MAX_TEAMS = 4
+MM_MAX_LOBBY = 16
+MM_MODE_REGION_FILTER = 1
+MM_MODE_PARTY_FILTER = 2
+MM_CFG_TIMING = 1
+NO_SLOT = 0xFFFFFFFF
+
+STATUS_NAMES = {
+    0: "MM_OK", -1: "MM_ERR_INVALID_ARG", -2: "MM_ERR_NO_DEVICE", -3: "MM_ERR_OOM",
+    -4: "MM_ERR_FULL", -5: "MM_ERR_HIP", -6: "MM_ERR_INTERNAL", -7: "MM_ERR_ABI",
+    -8: "MM_ERR_RANGE",
+}
+
+
+class MMRatingGroup(C.Structure):
+    _fields_ = [("from_", C.c_int32), ("to", C.c_int32)]
+
+
+class MMModeConfig(C.Structure):
+    _fields_ = [
+        ("team_size", C.c_uint32), ("teams", C.c_uint32), ("window", C.c_uint32),
+        ("flags", C.c_uint32), ("n_roles", C.c_uint32),
+        ("role_quota", C.c_uint8 * MM_MAX_ROLES),
+    ]
+
+
+class MMConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("n_groups", C.c_uint32),
+        ("groups", MMRatingGroup * MM_MAX_GROUPS), ("default_group", C.c_uint32),
+        ("n_modes", C.c_uint32), ("modes", MMModeConfig * MM_MAX_MODES),
+        ("capacity", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+    ]
+
+
+class MMStats(C.Structure):
+    _fields_ = [
+        ("pool_before", C.c_uint32), ("pool_after", C.c_uint32), ("matches", C.c_uint32),
+        ("players_matched", C.c_uint32), ("passes_max", C.c_uint32), ("chains", C.c_uint32),
+        ("pairs", C.c_uint64), ("scanned", C.c_uint64),
+        ("walk_ms", C.c_float), ("filter_ms", C.c_float), ("copy_ms", C.c_float),
+        ("total_ms", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class MMEnqueueStats(C.Structure):
+    _fields_ = [("accepted", C.c_uint32), ("rejected", C.c_uint32),
+                ("bucket_ms", C.c_float), ("total_ms", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class MMError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = int(status)
+        super().__init__("%s failed: %s (%d)" % (where, STATUS_NAMES.get(self.status, "?"), self.status))
+
+
+def cons_make(mode=0, region=0, party=0, role=0):
+    """MM_CONS_MAKE for scalars or numpy arrays."""
+    mode, region, party, role = (np.asarray(x, dtype=np.uint32) for x in (mode, region, party, role))
+    return ((mode & 0xF) | ((region & 0xFF) << 4) | ((party & 0xF) << 12) | ((role & 0xF) << 16)).astype(np.uint32)
+
+
+# Names every ABI library must export (suffixes after the prefix); tests/test_abi_symbols.py
+# cross-checks this list against include/mm_engine.h.
+ABI_FUNCTIONS = [
+    "engine_create", "engine_destroy", "reset", "find_rating_group", "enqueue", "cancel",
+    "tick", "matches", "queue_depth", "lobby_state",
+]
+PRODUCT_ONLY_FUNCTIONS = ["abi_version", "strerror", "config_default", "enqueue_device",
+                          "last_hip_error"]
+
+
+def bind(lib, prefix):
+    """Set argtypes/restype for the common ABI under `prefix` ('mm_' or 'mo_')."""
+    u32p = C.POINTER(C.c_uint32)
+    f = lambda n: getattr(lib, prefix + n)
+    f("engine_create").argtypes = [C.POINTER(MMConfig), C.POINTER(C.c_void_p)]
+    f("engine_create").restype = C.c_int
+    f("engine_destroy").argtypes = [C.c_void_p]
+    f("engine_destroy").restype = None
+    f("reset").argtypes = [C.c_void_p]
+    f("reset").restype = C.c_int
+    f("find_rating_group").argtypes = [C.POINTER(MMConfig), C.c_double, u32p]
+    f("find_rating_group").restype = C.c_int
+    f("enqueue").argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.POINTER(MMEnqueueStats)]
+    f("enqueue").restype = C.c_int
+    f("cancel").argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    f("cancel").restype = C.c_int
+    f("tick").argtypes = [C.c_void_p, C.c_uint32, u32p, C.POINTER(MMStats)]
+    f("tick").restype = C.c_int
+    f("matches").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p]
+    f("matches").restype = C.c_int
+    f("queue_depth").argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    f("queue_depth").restype = C.c_int
+    f("lobby_state").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p, C.c_void_p, C.c_void_p]
+    f("lobby_state").restype = C.c_int
+    return lib
+
+
+@dataclass
+class Matches:
+    """Result of one tick, in emission order."""
+    slots: np.ndarray   # (n, L) uint32, team order
+    score: np.ndarray   # (n,) float32
+    group: np.ndarray   # (n,) uint32
+    pass_: np.ndarray   # (n,) uint32
+    stats: dict
+
+    def __len__(self):
+        return int(self.slots.shape[0])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class EngineBase:
+    """Object wrapper over one ABI library.  Subclasses set `_lib` and `_prefix`."""
+
+    _lib = None
+    _prefix = "mm_"
+
+    def __init__(self, cfg: MMConfig):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        self._check(self._fn("engine_create")(C.byref(cfg), C.byref(self._h)), "engine_create")
+
+    # plumbing ------------------------------------------------------------------------
+    def _fn(self, name):
+        return getattr(self._lib, self._prefix + name)
+
+    def _check(self, rc, where):
+        if rc != 0:
+            raise MMError(rc, self._prefix + where)
+
+    def close(self):
+        if self._h:
+            self._fn("engine_destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ABI -----------------------------------------------------------------------------
+    def lobby_size(self, mode):
+        m = self.cfg.modes[mode]
+        return int(m.teams * m.team_size)
+
+    def reset(self):
+        self._check(self._fn("reset")(self._h), "reset")
+
+    def find_rating_group(self, rating):
+        g = C.c_uint32()
+        self._check(self._fn("find_rating_group")(C.byref(self.cfg), float(rating), C.byref(g)),
+                    "find_rating_group")
+        return int(g.value)
+
+    def enqueue(self, rating, cons, group=None):
+        rating = np.ascontiguousarray(rating, dtype=np.int32)
+        cons = np.ascontiguousarray(cons, dtype=np.uint32)
+        assert rating.shape == cons.shape and rating.ndim == 1
+        if group is not None:
+            group = np.ascontiguousarray(group, dtype=np.uint8)
+            assert group.shape == rating.shape
+        n = rating.shape[0]
+        slots = np.empty(n, dtype=np.uint32)
+        st = MMEnqueueStats()
+        self._check(self._fn("enqueue")(self._h, n, _ptr(rating), _ptr(cons), _ptr(group),
+                                        _ptr(slots), C.byref(st)), "enqueue")
+        self.last_enqueue_stats = st.as_dict()
+        return slots
+
+    def cancel(self, slots):
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        self._check(self._fn("cancel")(self._h, slots.shape[0], _ptr(slots)), "cancel")
+
+    def tick(self, mode=0) -> Matches:
+        n = C.c_uint32()
+        st = MMStats()
+        self._check(self._fn("tick")(self._h, mode, C.byref(n), C.byref(st)), "tick")
+        n = int(n.value)
+        L = self.lobby_size(mode)
+        slots = np.empty((n, L), dtype=np.uint32)
+        score = np.empty(n, dtype=np.float32)
+        group = np.empty(n, dtype=np.uint32)
+        pass_ = np.empty(n, dtype=np.uint32)
+        self._check(self._fn("matches")(self._h, 0, n, _ptr(slots), _ptr(score), _ptr(group),
+                                        _ptr(pass_)), "matches")
+        return Matches(slots, score, group, pass_, st.as_dict())
+
+    def queue_depth(self, mode=0):
+        out = np.zeros(self.cfg.n_groups, dtype=np.uint32)
+        self._check(self._fn("queue_depth")(self._h, mode, _ptr(out)), "queue_depth")
+        return out
+
+    def lobby_state(self, mode, group):
+        n = C.c_uint32()
+        slots = np.zeros(MM_MAX_LOBBY, dtype=np.uint32)
+        teams = np.zeros(MM_MAX_LOBBY, dtype=np.uint8)
+        self._check(self._fn("lobby_state")(self._h, mode, group, C.byref(n), _ptr(slots),
+                                            _ptr(teams)), "lobby_state")
+        k = int(n.value)
+        return slots[:k].copy(), teams[:k].copy()
