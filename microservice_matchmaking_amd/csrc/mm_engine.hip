@@ -1,0 +1,1294 @@
+// mm_engine.hip — MI355X (gfx950) implementation of include/mm_engine.h.
+//
+// One translation unit: HIP kernels + the C-ABI host code that drives them.
+// Path replaced: Matchmaking.Search.Worker.consume/5 (reference lib/search/worker.ex:291-324)
+// run under the canonical schedule of SURVEY.md §3.4 / docs/MATCH_CHECK.md ("Mode R"),
+// plus the bucketing hop in front of it (lib/generic/worker.ex:46-69).
+//
+// Device data layout (all HBM-resident, SoA, queue-ordered):
+//   chain = (game mode, rating group) — an independent FIFO + one open lobby
+//           (lib/application.ex:26-40, lib/models/lobby_state.ex:15-29).
+//   q_rating[chain][cap] i32, q_cons[chain][cap] u32, q_slot[chain][cap] u32
+//           the broker queue `matchmaking.queues.<group>` restricted to one mode, head at
+//           index 0; always in ascending arrival order (MATCH_CHECK.md §4).
+//   chains[chain]   ChainDev: queue length, the open lobby (LobbyState record), per-tick
+//           counters.
+//   state[slot] u8  ActiveUser mirror: 1 = in queue, 2 = cancelled (lib/models/active_user.ex).
+//   out_*[group][..] per-group emission logs of the last tick (team-ordered slots, score, pass).
+//
+// Kernels:
+//   k_bucket_count / k_bucket_scan / k_bucket_scatter   stable multi-way partition of an
+//           arrival batch into chain tails (A1 bucketing); HBM streaming, wave-ballot ranks.
+//   k_cancel, k_purge   ActiveUser.remove_user + the "vanish when popped" rule.
+//   k_walk   one workgroup per chain: LDS-staged tiles of the queue, wave-0 first-fit chain
+//           (ballot + ffs arg-min over queue position), in-place survivor compaction.
+//           The chain is inherently sequential (each match decides the next anchor), so
+//           the parallelism is: 64 candidates per anchor step, tile load/compaction on the
+//           other waves, and independent chains on independent CUs.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/mm_engine.h"
+
+// ------------------------------------------------------------------------------------
+// device-side structures
+// ------------------------------------------------------------------------------------
+
+#define MM_NO_SLOT 0xFFFFFFFFu
+#define MM_ST_FREE 0
+#define MM_ST_LIVE 1
+#define MM_ST_CANCELLED 2
+
+#define MM_ERRF_QUEUE_OVERFLOW 1u
+#define MM_ERRF_OUT_OVERFLOW 2u
+#define MM_ERRF_SEAT_INVARIANT 4u
+#define MM_ERRF_PASS_LIMIT 8u
+
+struct LobbyDev {                                 // the record LobbyState stores
+    uint32_t n;
+    uint32_t cnt[MM_MAX_TEAMS];
+    uint32_t slot[MM_MAX_TEAMS][8];
+    int32_t  rating[MM_MAX_TEAMS][8];
+    uint32_t cons[MM_MAX_TEAMS][8];
+};
+
+struct ChainDev {
+    uint32_t len;        // queue length
+    uint32_t head_state; // set by k_purge: 0 = queue was empty, 1 = head alive, 2 = head cancelled
+    uint32_t n_out;      // lobbies emitted in the last tick
+    uint32_t passes;
+    uint32_t err;
+    uint32_t purged;     // entries k_purge removed (folded into `before` by k_walk)
+    uint32_t before;     // queue + lobby population when the tick began
+    uint32_t pad;
+    unsigned long long pairs;
+    unsigned long long scanned;
+    LobbyDev lobby;
+};
+
+struct ModeDev {
+    uint32_t team_size, teams, window, eqmask, n_roles, L;
+    uint32_t quota[MM_MAX_ROLES];
+};
+
+struct BucketCfg {
+    uint32_t n_groups, n_modes, default_group, capacity;
+    int32_t from[MM_MAX_GROUPS], to[MM_MAX_GROUPS];
+    uint32_t n_roles[MM_MAX_MODES];
+    uint32_t quota_mask[MM_MAX_MODES];  // bit r set = role r seatable
+};
+
+#define BK_THREADS 256
+#define BK_WAVES 4
+#define BK_PER_WAVE 512                       // elements per wave per block
+#define BK_CHUNK (BK_WAVES * BK_PER_WAVE)     // elements per block
+#define BK_MAXC (MM_MAX_GROUPS * MM_MAX_MODES)
+#define BK_INVALID 0xFFFFu
+
+#define WK_THREADS 256
+#define WK_TILE 4096
+
+static __device__ __forceinline__ uint32_t dev_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// generic/worker.ex:46-53 on an int32 rating
+static __device__ __forceinline__ uint32_t dev_rating_group(const BucketCfg& B, int32_t r)
+{
+    uint32_t g = B.default_group;
+    for (int k = (int)B.n_groups - 1; k >= 0; --k)
+        if (r >= B.from[k] && r <= B.to[k]) g = (uint32_t)k;   // lowest matching index wins
+    return g;
+}
+
+static __device__ __forceinline__ uint32_t dev_chain_of(const BucketCfg& B, int32_t r, uint32_t cons,
+                                                         const uint8_t* group, uint32_t i)
+{
+    const uint32_t mode = cons & 0xFu, role = (cons >> 16) & 0xFu;
+    if (mode >= B.n_modes || role >= B.n_roles[mode] || !((B.quota_mask[mode] >> role) & 1u))
+        return BK_INVALID;
+    const uint32_t g = group ? (uint32_t)group[i] : dev_rating_group(B, r);
+    return mode * B.n_groups + g;
+}
+
+// Orders LDS traffic between the lanes of ONE wave: everything written before it (by any
+// lane) is visible to every lane after it.  The hardware executes a wave's LDS ops in
+// order; the fence stops the compiler from forwarding stale register copies across it.
+static __device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Up to 256 per-chain counters of one wave, held in registers: lane l owns chains
+// l, l+64, l+128, l+192.  Reads are wave shuffles, updates touch one lane.
+struct LaneCounters {
+    uint32_t v0, v1, v2, v3;
+};
+static __device__ __forceinline__ uint32_t lc_get(const LaneCounters& k, uint32_t c)
+{
+    const uint32_t x = c < 64u ? k.v0 : c < 128u ? k.v1 : c < 192u ? k.v2 : k.v3;   // c is wave-uniform
+    return (uint32_t)__shfl((int)x, (int)(c & 63u));
+}
+static __device__ __forceinline__ void lc_add(LaneCounters& k, uint32_t c, uint32_t n, int lane)
+{
+    if ((uint32_t)lane == (c & 63u)) {
+        if (c < 64u) k.v0 += n;
+        else if (c < 128u) k.v1 += n;
+        else if (c < 192u) k.v2 += n;
+        else k.v3 += n;
+    }
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave.
+static __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = (uint32_t)__shfl((int)v, lane >= d ? lane - d : lane);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// bucketing (enqueue) kernels
+// ------------------------------------------------------------------------------------
+
+// Per-wave histogram of chain ids: wave_hist[(block*4 + wave) * n_chains + chain].
+__global__ __launch_bounds__(BK_THREADS) void k_bucket_count(uint32_t n, const int32_t* __restrict__ rating,
+                                                             const uint32_t* __restrict__ cons,
+                                                             const uint8_t* __restrict__ group, BucketCfg B,
+                                                             uint32_t n_chains, uint32_t* __restrict__ wave_hist,
+                                                             uint32_t* __restrict__ rejected)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    LaneCounters hist = { 0u, 0u, 0u, 0u };
+    uint32_t rej = 0;
+    const uint32_t base = blockIdx.x * BK_CHUNK + wave * BK_PER_WAVE;
+    for (uint32_t r = 0; r < BK_PER_WAVE / 64; ++r) {
+        const uint32_t i = base + r * 64 + lane;
+        const bool valid = i < n;
+        uint32_t ch = BK_INVALID;
+        if (valid) ch = dev_chain_of(B, rating[i], cons[i] & MM_CONS_USER_MASK, group, i);
+        rej += (valid && ch == BK_INVALID) ? 1u : 0u;
+        unsigned long long todo = __ballot(ch != BK_INVALID);
+        while (todo) {
+            const int l = __ffsll(todo) - 1;
+            const uint32_t c0 = (uint32_t)__shfl((int)ch, l);
+            const unsigned long long m = __ballot(ch == c0);
+            lc_add(hist, c0, (uint32_t)__popcll(m), lane);
+            todo &= ~m;
+        }
+    }
+    if (__ballot(rej != 0)) {   // rare: reduce the per-lane reject counts
+        const uint32_t s = wave_incl_scan(rej, lane);
+        if (lane == 63) atomicAdd(rejected, s);
+    }
+    const uint32_t row = (blockIdx.x * BK_WAVES + wave) * n_chains;
+    if ((uint32_t)lane < n_chains) wave_hist[row + lane] = hist.v0;
+    if ((uint32_t)lane + 64u < n_chains) wave_hist[row + lane + 64u] = hist.v1;
+    if ((uint32_t)lane + 128u < n_chains) wave_hist[row + lane + 128u] = hist.v2;
+    if ((uint32_t)lane + 192u < n_chains) wave_hist[row + lane + 192u] = hist.v3;
+}
+
+// Exclusive scan of wave_hist down the wave axis, per chain, seeded with the chain's
+// current length; updates the chain lengths.  One block.
+__global__ __launch_bounds__(BK_THREADS) void k_bucket_scan(uint32_t n_rows, uint32_t n_chains,
+                                                            uint32_t* __restrict__ wave_hist,
+                                                            ChainDev* __restrict__ chains, uint32_t capacity)
+{
+    __shared__ uint32_t wtot[BK_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = (n_rows + BK_THREADS - 1) / BK_THREADS;
+    const uint32_t r0 = dev_min_u32(tid * per, n_rows), r1 = dev_min_u32(r0 + per, n_rows);
+    for (uint32_t c = 0; c < n_chains; ++c) {
+        uint32_t s = 0;
+        for (uint32_t r = r0; r < r1; ++r) s += wave_hist[r * n_chains + c];
+        const uint32_t incl = wave_incl_scan(s, lane);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t off = chains[c].len;
+        for (int w = 0; w < wave; ++w) off += wtot[w];
+        uint32_t run = off + incl - s;
+        for (uint32_t r = r0; r < r1; ++r) {
+            const uint32_t h = wave_hist[r * n_chains + c];
+            wave_hist[r * n_chains + c] = run;
+            run += h;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t total = chains[c].len;
+            for (int w = 0; w < BK_WAVES; ++w) total += wtot[w];
+            if (total > capacity) { chains[c].err |= MM_ERRF_QUEUE_OVERFLOW; total = capacity; }
+            chains[c].len = total;
+        }
+        __syncthreads();
+    }
+}
+
+// Stable scatter into the chain tails.  wave_base = scanned wave_hist.
+__global__ __launch_bounds__(BK_THREADS) void k_bucket_scatter(uint32_t n, const int32_t* __restrict__ rating,
+                                                               const uint32_t* __restrict__ cons,
+                                                               const uint8_t* __restrict__ group, BucketCfg B,
+                                                               uint32_t n_chains,
+                                                               const uint32_t* __restrict__ wave_base,
+                                                               uint32_t first_slot, int32_t* __restrict__ q_rating,
+                                                               uint32_t* __restrict__ q_cons,
+                                                               uint32_t* __restrict__ q_slot,
+                                                               uint8_t* __restrict__ state,
+                                                               uint32_t* __restrict__ out_slot)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t row = (blockIdx.x * BK_WAVES + wave) * n_chains;
+    LaneCounters cur = { 0u, 0u, 0u, 0u };
+    if ((uint32_t)lane < n_chains) cur.v0 = wave_base[row + lane];
+    if ((uint32_t)lane + 64u < n_chains) cur.v1 = wave_base[row + lane + 64u];
+    if ((uint32_t)lane + 128u < n_chains) cur.v2 = wave_base[row + lane + 128u];
+    if ((uint32_t)lane + 192u < n_chains) cur.v3 = wave_base[row + lane + 192u];
+    const uint32_t base = blockIdx.x * BK_CHUNK + wave * BK_PER_WAVE;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t r = 0; r < BK_PER_WAVE / 64; ++r) {
+        const uint32_t i = base + r * 64 + lane;
+        const bool valid = i < n;
+        uint32_t ch = BK_INVALID, cn = 0;
+        int32_t rt = 0;
+        if (valid) {
+            rt = rating[i];
+            cn = cons[i] & MM_CONS_USER_MASK;
+            ch = dev_chain_of(B, rt, cn, group, i);
+        }
+        const uint32_t slot = (uint32_t)(((unsigned long long)first_slot + i) % B.capacity);
+        if (valid && out_slot) out_slot[i] = (ch == BK_INVALID) ? MM_NO_SLOT : slot;
+        unsigned long long todo = __ballot(ch != BK_INVALID);
+        while (todo) {
+            const int l = __ffsll(todo) - 1;
+            const uint32_t c0 = (uint32_t)__shfl((int)ch, l);
+            const unsigned long long m = __ballot(ch == c0);
+            const uint32_t start = lc_get(cur, c0);
+            if (ch == c0) {
+                const uint32_t pos = start + (uint32_t)__popcll(m & lt);
+                if (pos < B.capacity) {
+                    const size_t o = (size_t)c0 * B.capacity + pos;
+                    q_rating[o] = rt;
+                    q_cons[o] = cn;
+                    q_slot[o] = slot;
+                    state[slot] = MM_ST_LIVE;
+                }
+            }
+            lc_add(cur, c0, (uint32_t)__popcll(m), lane);
+            todo &= ~m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// liveness (ActiveUser) kernels
+// ------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_cancel(uint32_t n, const uint32_t* __restrict__ slots,
+                                                uint8_t* __restrict__ state)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) state[slots[i]] = MM_ST_CANCELLED;
+}
+
+// One block per chain of the ticked mode: records whether the head of the queue was
+// cancelled (MATCH_CHECK.md §4: decides whether the first live attempt sees the stale
+// lobby) and removes cancelled entries in place, appending their slots to `released`.
+__global__ __launch_bounds__(WK_THREADS) void k_purge(uint32_t mode, uint32_t n_groups, uint32_t capacity,
+                                                      ChainDev* __restrict__ chains,
+                                                      int32_t* __restrict__ q_rating, uint32_t* __restrict__ q_cons,
+                                                      uint32_t* __restrict__ q_slot, uint8_t* __restrict__ state,
+                                                      uint32_t* __restrict__ released,
+                                                      uint32_t* __restrict__ n_released)
+{
+    __shared__ uint32_t wtot[WK_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = mode * n_groups + blockIdx.x;
+    const size_t qo = (size_t)c * capacity;
+    const uint32_t m = chains[c].len;
+    if (m == 0) {
+        if (tid == 0) { chains[c].head_state = 0; chains[c].purged = 0; }
+        return;
+    }
+    const uint32_t head_state = state[q_slot[qo]] != MM_ST_LIVE ? 2u : 1u;
+    uint32_t wr = 0;
+    for (uint32_t rd = 0; rd < m; rd += WK_THREADS) {
+        const uint32_t i = rd + tid;
+        int32_t rt = 0;
+        uint32_t cn = 0, sl = 0;
+        bool live = false;
+        if (i < m) {
+            rt = q_rating[qo + i];
+            cn = q_cons[qo + i];
+            sl = q_slot[qo + i];
+            live = state[sl] == MM_ST_LIVE;
+            if (!live) {
+                state[sl] = MM_ST_FREE;
+                released[atomicAdd(n_released, 1u)] = sl;
+            }
+        }
+        const unsigned long long bm = __ballot(live);
+        if (lane == 0) wtot[wave] = (uint32_t)__popcll(bm);
+        __syncthreads();   // also orders the reads above before the in-place writes below
+        uint32_t off = wr, tot = 0;
+        for (int w = 0; w < WK_THREADS / 64; ++w) {
+            if (w < wave) off += wtot[w];
+            tot += wtot[w];
+        }
+        if (live) {
+            const uint32_t d = off + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+            q_rating[qo + d] = rt;
+            q_cons[qo + d] = cn;
+            q_slot[qo + d] = sl;
+        }
+        wr += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        chains[c].len = wr;
+        chains[c].head_state = head_state;
+        chains[c].purged = m - wr;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reset(uint32_t n_chains, ChainDev* __restrict__ chains)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t words = (uint32_t)(sizeof(ChainDev) / 4);
+    if (i < n_chains * words) ((uint32_t*)chains)[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------
+// the walk kernel: Search.Worker.consume/5 to quiescence, one workgroup per chain
+// ------------------------------------------------------------------------------------
+
+struct WalkParams {
+    uint32_t mode, n_groups, capacity, purge;
+    uint32_t out_cap;          // lobbies per group the out_* arrays can hold
+    uint32_t out_slot_stride;  // u32 per group in out_slots
+    uint32_t out_rec_stride;   // records per group in out_score / out_pass
+    uint32_t max_passes;
+    ModeDev M;
+    ChainDev* chains;
+    int32_t* q_rating;
+    uint32_t* q_cons;
+    uint32_t* q_slot;
+    uint8_t* state;
+    uint32_t* released;
+    uint32_t* n_released;
+    uint32_t* out_slots;       // [n_groups][out_slot_stride], team-ordered slots, L per lobby
+    float* out_score;          // [n_groups][out_rec_stride]
+    uint32_t* out_pass;        // [n_groups][out_rec_stride]
+};
+
+// Discipline for the LDS lobby inside wave 0: every lane may READ it between two
+// wave_sync() points; only lane 0 WRITES it, bracketed by wave_sync() on both sides.
+
+// docs/MATCH_CHECK.md §2.1-2.3: the team `(r, cn)` would be seated in, or -1.  Read-only.
+static __device__ int lobby_pick_team(const LobbyDev& lb, const ModeDev& M, int32_t r, uint32_t cn)
+{
+    int at = -1;
+    for (uint32_t t = 0; t < M.teams; ++t)
+        if (lb.cnt[t]) { at = (int)t; break; }
+    if (at >= 0) {
+        const int32_t ar = lb.rating[at][0];
+        const uint32_t ac = lb.cons[at][0];
+        const uint32_t d = r >= ar ? (uint32_t)r - (uint32_t)ar : (uint32_t)ar - (uint32_t)r;
+        if (d > M.window) return -1;
+        if ((cn ^ ac) & M.eqmask) return -1;
+    }
+    const uint32_t role = (cn >> 16) & 0xFu;
+    int best = -1;
+    long long best_sum = 0;
+    for (uint32_t t = 0; t < M.teams; ++t) {
+        uint32_t have = 0;
+        long long sum = 0;
+        for (uint32_t k = 0; k < lb.cnt[t]; ++k) {
+            have += ((lb.cons[t][k] >> 16) & 0xFu) == role ? 1u : 0u;
+            sum += lb.rating[t][k];
+        }
+        if (have >= M.quota[role]) continue;
+        if (best < 0 || sum < best_sum) { best = (int)t; best_sum = sum; }
+    }
+    return best;
+}
+
+// docs/MATCH_CHECK.md §2.4: append to the chosen team.
+static __device__ int lobby_try_seat(LobbyDev& lb, const ModeDev& M, int32_t r, uint32_t cn, uint32_t slot, int lane)
+{
+    const int best = lobby_pick_team(lb, M, r, cn);
+    wave_sync();
+    if (best >= 0 && lane == 0) {
+        const uint32_t k = lb.cnt[best];
+        lb.slot[best][k] = slot;
+        lb.rating[best][k] = r;
+        lb.cons[best][k] = cn;
+        lb.cnt[best] = k + 1;
+        lb.n = lb.n + 1;
+    }
+    wave_sync();
+    return best;
+}
+
+// remove_inactive_players/1 (search/worker.ex:267-280) on the LDS lobby; the released
+// slots go to the host so it can recycle them.
+static __device__ void lobby_filter(LobbyDev& lb, const ModeDev& M, uint8_t* state, uint32_t* released,
+                                    uint32_t* n_released, int lane)
+{
+    wave_sync();
+    if (lane == 0) {
+        for (uint32_t t = 0; t < M.teams; ++t) {
+            uint32_t w = 0;
+            const uint32_t n = lb.cnt[t];
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t sl = lb.slot[t][k];
+                if (state[sl] == MM_ST_LIVE) {
+                    const int32_t r = lb.rating[t][k];
+                    const uint32_t cn = lb.cons[t][k];
+                    lb.slot[t][w] = sl;
+                    lb.rating[t][w] = r;
+                    lb.cons[t][w] = cn;
+                    ++w;
+                } else {
+                    state[sl] = MM_ST_FREE;
+                    released[atomicAdd(n_released, 1u)] = sl;
+                }
+            }
+            lb.n = lb.n - (n - w);
+            lb.cnt[t] = w;
+        }
+    }
+    wave_sync();
+}
+
+static __device__ bool lobby_has_cancelled(const LobbyDev& lb, const ModeDev& M, const uint8_t* state)
+{
+    bool any = false;
+    for (uint32_t t = 0; t < M.teams; ++t)
+        for (uint32_t k = 0; k < lb.cnt[t]; ++k)
+            if (state[lb.slot[t][k]] != MM_ST_LIVE) any = true;
+    return any;
+}
+
+__global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
+{
+    __shared__ int32_t t_rating[WK_TILE];
+    __shared__ uint32_t t_cons[WK_TILE];
+    __shared__ uint32_t t_slot[WK_TILE];
+    __shared__ uint32_t t_mask[WK_TILE / 32];       // bit = element left the queue (seated)
+    __shared__ uint32_t t_pref[WK_TILE / 32];       // exclusive survivor prefix per mask word
+    __shared__ LobbyDev lb;
+    __shared__ uint32_t s_changed, s_total, s_w0tot;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = blockIdx.x;
+    const uint32_t c = P.mode * P.n_groups + g;
+    const ModeDev& M = P.M;
+    const size_t qo = (size_t)c * P.capacity;
+    int32_t* const qr = P.q_rating + qo;
+    uint32_t* const qc = P.q_cons + qo;
+    uint32_t* const qs = P.q_slot + qo;
+    ChainDev* const ch = P.chains + c;
+
+    // ---- load the stored lobby (LobbyState.get_state) ----
+    {
+        const uint32_t words = (uint32_t)(sizeof(LobbyDev) / 4);
+        const uint32_t* src = (const uint32_t*)&ch->lobby;
+        uint32_t* dst = (uint32_t*)&lb;
+        for (uint32_t i = tid; i < words; i += WK_THREADS) dst[i] = src[i];
+    }
+    uint32_t m = ch->len;
+    const uint32_t head_state = P.purge ? ch->head_state : 0u;
+    const uint32_t before = m + ch->lobby.n + (P.purge ? ch->purged : 0u);
+    __syncthreads();
+
+    // wave-0 chain state (uniform across the wave)
+    bool first_stale = false;
+    uint32_t n_out = 0, err = 0;
+    unsigned long long pairs = 0, scanned = 0;
+    uint32_t passes = 0;
+
+    if (wave == 0 && head_state != 0u) {
+        // deferred effect of mm_cancel on the stored lobby (MATCH_CHECK.md §4): an empty
+        // queue means no attempt, so the lobby stays as stored; a cancelled head filters it
+        // before anyone is judged; a live head is judged against the stale lobby first.
+        if (head_state == 1u && lobby_has_cancelled(lb, M, P.state)) first_stale = true;
+        else lobby_filter(lb, M, P.state, P.released, P.n_released, lane);
+    }
+
+    while (m > 0) {
+        bool changed = false;
+        uint32_t wr = 0;
+        scanned += m;
+        for (uint32_t rd = 0; rd < m; rd += WK_TILE) {
+            const uint32_t cnt = dev_min_u32(WK_TILE, m - rd);
+            // ---- stage the tile: coalesced SoA loads HBM -> LDS ----
+            for (uint32_t i = tid; i < cnt; i += WK_THREADS) {
+                t_rating[i] = qr[rd + i];
+                t_cons[i] = qc[rd + i];
+                t_slot[i] = qs[rd + i];
+            }
+            if (tid < WK_TILE / 32) t_mask[tid] = 0;
+            __syncthreads();
+
+            // ---- wave 0: the first-fit chain over the tile ----
+            if (wave == 0) {
+                uint32_t p = 0;
+                if (first_stale) {
+                    // first attempt after a cancel: judged against the stale lobby, then filter
+                    first_stale = false;
+                    if (lb.n) pairs += 1;
+                    const int t = lobby_try_seat(lb, M, t_rating[0], t_cons[0], t_slot[0], lane);
+                    lobby_filter(lb, M, P.state, P.released, P.n_released, lane);
+                    if (t >= 0) {
+                        changed = true;
+                        if (lane == 0) atomicOr(&t_mask[0], 1u);
+                    }
+                    p = 1;
+                }
+                while (p < cnt) {
+                    if (lb.n == 0) {
+                        // empty lobby: the popped player opens it (MATCH_CHECK.md §2.1)
+                        const int t = lobby_try_seat(lb, M, t_rating[p], t_cons[p], t_slot[p], lane);
+                        if (t < 0) err |= MM_ERRF_SEAT_INVARIANT;
+                        if (lane == 0) atomicOr(&t_mask[p >> 5], 1u << (p & 31));
+                        changed = true;
+                        ++p;
+                        continue;
+                    }
+                    // anchor + free seats per role
+                    int at = 0;
+                    for (uint32_t t = 0; t < M.teams; ++t)
+                        if (lb.cnt[t]) { at = (int)t; break; }
+                    const int32_t ar = lb.rating[at][0];
+                    const uint32_t ac = lb.cons[at][0];
+                    uint32_t total_free = M.L - lb.n;
+                    // 64 candidates, one per lane
+                    const uint32_t i = p + lane;
+                    const bool valid = i < cnt;
+                    const uint32_t nvalid = dev_min_u32(64u, cnt - p);
+                    int32_t r = 0;
+                    uint32_t cn = 0;
+                    if (valid) { r = t_rating[i]; cn = t_cons[i]; }
+                    const uint32_t d = r >= ar ? (uint32_t)r - (uint32_t)ar : (uint32_t)ar - (uint32_t)r;
+                    const bool ok = valid && d <= M.window && (((cn ^ ac) & M.eqmask) == 0);
+                    const uint32_t role = (cn >> 16) & 0xFu;
+                    unsigned long long S = 0;
+                    for (uint32_t rr = 0; rr < M.n_roles; ++rr) {
+                        uint32_t have = 0;
+                        for (uint32_t t = 0; t < M.teams; ++t)
+                            for (uint32_t k = 0; k < lb.cnt[t]; ++k)
+                                have += ((lb.cons[t][k] >> 16) & 0xFu) == rr ? 1u : 0u;
+                        uint32_t fr = M.teams * M.quota[rr] - have;
+                        unsigned long long mk = __ballot(ok && role == rr);
+                        while (fr && mk) {                 // first `fr` candidates of the role
+                            S |= mk & (~mk + 1ull);
+                            mk &= mk - 1ull;
+                            --fr;
+                        }
+                    }
+                    if (S == 0) {
+                        pairs += nvalid;
+                        p += 64;
+                        continue;
+                    }
+                    changed = true;
+                    const uint32_t nS = (uint32_t)__popcll(S);
+                    const bool fills = nS >= total_free;
+                    const uint32_t last = 63u - (uint32_t)__clzll((long long)S);   // highest seated lane
+                    unsigned long long todo = S;
+                    while (todo) {
+                        const uint32_t b = (uint32_t)__ffsll(todo) - 1u;
+                        todo &= todo - 1ull;
+                        const uint32_t e = p + b;
+                        const int t = lobby_try_seat(lb, M, t_rating[e], t_cons[e], t_slot[e], lane);
+                        if (t < 0) err |= MM_ERRF_SEAT_INVARIANT;
+                    }
+                    if ((S >> lane) & 1ull) atomicOr(&t_mask[(p + lane) >> 5], 1u << ((p + lane) & 31));
+                    if (!fills) {
+                        pairs += nvalid;
+                        p += 64;
+                        continue;
+                    }
+                    // ---- is_filled: emit in team order (search/worker.ex:313-319) ----
+                    if (lb.n != M.L) err |= MM_ERRF_SEAT_INVARIANT;
+                    wave_sync();
+                    if (lane == 0) {
+                        if (n_out < P.out_cap) {
+                            long long smin = 0, smax = 0;
+                            uint32_t k = 0;
+                            uint32_t* os = P.out_slots + (size_t)g * P.out_slot_stride + (size_t)n_out * M.L;
+                            for (uint32_t t = 0; t < M.teams; ++t) {
+                                long long sm = 0;
+                                for (uint32_t j = 0; j < lb.cnt[t]; ++j) {
+                                    os[k++] = lb.slot[t][j];
+                                    sm += lb.rating[t][j];
+                                }
+                                if (t == 0 || sm < smin) smin = sm;
+                                if (t == 0 || sm > smax) smax = sm;
+                            }
+                            P.out_score[(size_t)g * P.out_rec_stride + n_out] =
+                                (float)(int32_t)(smax - smin) / (float)(int32_t)M.team_size;
+                            P.out_pass[(size_t)g * P.out_rec_stride + n_out] = passes;
+                        }
+                        lb.n = 0;
+                        for (uint32_t t = 0; t < M.teams; ++t) lb.cnt[t] = 0;
+                    }
+                    wave_sync();
+                    if (n_out >= P.out_cap) err |= MM_ERRF_OUT_OVERFLOW;
+                    ++n_out;
+                    pairs += last + 1u;
+                    p += last + 1u;
+                }
+            }
+            __syncthreads();
+
+            // ---- survivors back to the queue, in place, order preserved (requeue) ----
+            const uint32_t nwords = (cnt + 31u) >> 5;
+            if (tid < WK_TILE / 32) {
+                uint32_t sv = 0;
+                if ((uint32_t)tid < nwords) {
+                    uint32_t vm = 0xFFFFFFFFu;
+                    if ((uint32_t)tid == nwords - 1u && (cnt & 31u)) vm = (1u << (cnt & 31u)) - 1u;
+                    sv = (uint32_t)__popc(~t_mask[tid] & vm);
+                }
+                const uint32_t incl = wave_incl_scan(sv, lane);
+                t_pref[tid] = incl - sv;
+                if (tid == 63) s_w0tot = incl;
+                if (tid == WK_TILE / 32 - 1) s_total = incl;   // wave 1's total, fixed up below
+            }
+            __syncthreads();
+            const uint32_t w0tot = s_w0tot;
+            const uint32_t total = w0tot + s_total;
+            for (uint32_t i = tid; i < cnt; i += WK_THREADS) {
+                const uint32_t w = i >> 5, b = i & 31u;
+                const uint32_t mw = t_mask[w];
+                if (!((mw >> b) & 1u)) {
+                    const uint32_t dpos = wr + t_pref[w] + (w >= 64u ? w0tot : 0u) +
+                                          (uint32_t)__popc(~mw & ((1u << b) - 1u));
+                    qr[dpos] = t_rating[i];
+                    qc[dpos] = t_cons[i];
+                    qs[dpos] = t_slot[i];
+                }
+            }
+            wr += total;
+            __syncthreads();
+        }
+        // ---- end of pass: quiescence test (MATCH_CHECK.md §4) ----
+        if (tid == 0) s_changed = changed ? 1u : 0u;
+        __syncthreads();
+        const uint32_t chg = s_changed;
+        m = wr;
+        ++passes;
+        if (!chg) break;
+        if (passes >= P.max_passes) { err |= MM_ERRF_PASS_LIMIT; break; }
+        __syncthreads();
+    }
+
+    // ---- store the lobby back (LobbyState.update_state) and the tick counters ----
+    __syncthreads();
+    {
+        const uint32_t words = (uint32_t)(sizeof(LobbyDev) / 4);
+        uint32_t* dst = (uint32_t*)&ch->lobby;
+        const uint32_t* src = (const uint32_t*)&lb;
+        for (uint32_t i = tid; i < words; i += WK_THREADS) dst[i] = src[i];
+    }
+    if (tid == 0) {
+        ch->len = m;
+        ch->head_state = 0;
+        ch->purged = 0;
+        ch->before = before;
+        ch->n_out = n_out;
+        ch->passes = passes;
+        ch->pairs = pairs;
+        ch->scanned = scanned;
+        ch->err |= err;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side: the C ABI
+// ------------------------------------------------------------------------------------
+
+struct mm_engine {
+    mm_config cfg;
+    uint32_t n_chains;
+    hipStream_t stream;
+    hipEvent_t ev[4];
+    int last_hip;
+    // device
+    int32_t* d_q_rating;
+    uint32_t* d_q_cons;
+    uint32_t* d_q_slot;
+    ChainDev* d_chains;
+    uint8_t* d_state;
+    uint32_t* d_released;
+    uint32_t* d_counters;      // [0] n_released, [1] rejected
+    uint32_t* d_wave_hist;
+    size_t wave_hist_rows;
+    int32_t* d_in_rating;      // staging for host-pointer enqueue
+    uint32_t* d_in_cons;
+    uint8_t* d_in_group;
+    uint32_t* d_in_slot;       // also cancel staging
+    size_t in_cap;
+    uint32_t* d_out_slots;
+    float* d_out_score;
+    uint32_t* d_out_pass;
+    uint32_t out_slot_stride, out_rec_stride;
+    // host
+    ChainDev* h_chains;        // pinned, n_chains
+    uint32_t* h_counters;      // pinned, 2
+    std::vector<uint8_t> h_state;
+    uint32_t next_slot;
+    uint32_t cancel_pending;
+    std::vector<uint32_t> r_slots, r_group, r_pass, r_released;
+    std::vector<float> r_score;
+    uint32_t r_n, r_L;
+};
+
+static double host_now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+#define HIPCHK(e, call)                                   \
+    do {                                                  \
+        hipError_t _rc = (call);                          \
+        if (_rc != hipSuccess) {                          \
+            (e)->last_hip = (int)_rc;                     \
+            return _rc == hipErrorOutOfMemory ? MM_ERR_OOM : MM_ERR_HIP; \
+        }                                                 \
+    } while (0)
+
+extern "C" uint32_t mm_abi_version(void) { return MM_ABI_VERSION; }
+
+extern "C" const char* mm_strerror(int status)
+{
+    switch (status) {
+    case MM_OK: return "ok";
+    case MM_ERR_INVALID_ARG: return "invalid argument";
+    case MM_ERR_NO_DEVICE: return "no usable HIP device";
+    case MM_ERR_OOM: return "out of memory";
+    case MM_ERR_FULL: return "pool capacity exhausted";
+    case MM_ERR_HIP: return "HIP runtime error";
+    case MM_ERR_INTERNAL: return "device-side invariant violated";
+    case MM_ERR_ABI: return "ABI version mismatch";
+    case MM_ERR_RANGE: return "match range out of bounds";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int mm_config_default(mm_config* cfg)
+{
+    if (!cfg) return MM_ERR_INVALID_ARG;
+    memset(cfg, 0, sizeof(*cfg));
+    static const int32_t ref[7][2] = { {0, 1499}, {1500, 1999}, {2000, 2499}, {2500, 2999},
+                                       {3000, 3499}, {3500, 3999}, {4000, 5000} };
+    cfg->abi_version = MM_ABI_VERSION;
+    cfg->n_groups = 7;
+    for (int g = 0; g < 7; ++g) { cfg->groups[g].from = ref[g][0]; cfg->groups[g].to = ref[g][1]; }
+    cfg->default_group = 7 / 2 + 1;
+    cfg->n_modes = 1;
+    cfg->modes[0].team_size = 1;
+    cfg->modes[0].teams = 2;
+    cfg->modes[0].window = 50;
+    cfg->modes[0].n_roles = 1;
+    cfg->modes[0].role_quota[0] = 1;
+    cfg->capacity = 1u << 20;
+    cfg->device = 0;
+    return MM_OK;
+}
+
+extern "C" int mm_find_rating_group(const mm_config* cfg, double rating, uint32_t* group)
+{
+    if (!cfg || !group) return MM_ERR_INVALID_ARG;
+    uint32_t g = cfg->default_group;
+    if (rating == rating) {
+        for (uint32_t k = 0; k < cfg->n_groups && k < MM_MAX_GROUPS; ++k)
+            if (rating >= (double)cfg->groups[k].from && rating <= (double)cfg->groups[k].to) { g = k; break; }
+    }
+    *group = g;
+    return MM_OK;
+}
+
+static int cfg_validate(const mm_config* c)
+{
+    if (c->abi_version != MM_ABI_VERSION) return MM_ERR_ABI;
+    if (c->n_groups < 1 || c->n_groups > MM_MAX_GROUPS) return MM_ERR_INVALID_ARG;
+    if (c->default_group >= c->n_groups) return MM_ERR_INVALID_ARG;
+    if (c->n_modes < 1 || c->n_modes > MM_MAX_MODES) return MM_ERR_INVALID_ARG;
+    if (c->capacity < 1 || c->capacity > (1u << 28)) return MM_ERR_INVALID_ARG;
+    for (uint32_t m = 0; m < c->n_modes; ++m) {
+        const mm_mode_config* mc = &c->modes[m];
+        if (mc->team_size < 1 || mc->team_size > 8) return MM_ERR_INVALID_ARG;
+        if (mc->teams < 2 || mc->teams > MM_MAX_TEAMS) return MM_ERR_INVALID_ARG;
+        if (mc->teams * mc->team_size > MM_MAX_LOBBY) return MM_ERR_INVALID_ARG;
+        if (mc->n_roles < 1 || mc->n_roles > MM_MAX_ROLES) return MM_ERR_INVALID_ARG;
+        if (mc->window > 0x3FFFFFFFu) return MM_ERR_INVALID_ARG;
+        uint32_t s = 0;
+        for (uint32_t r = 0; r < mc->n_roles; ++r) s += mc->role_quota[r];
+        if (s != mc->team_size) return MM_ERR_INVALID_ARG;
+    }
+    return MM_OK;
+}
+
+static BucketCfg make_bucket_cfg(const mm_config& c)
+{
+    BucketCfg B;
+    memset(&B, 0, sizeof(B));
+    B.n_groups = c.n_groups;
+    B.n_modes = c.n_modes;
+    B.default_group = c.default_group;
+    B.capacity = c.capacity;
+    for (uint32_t g = 0; g < c.n_groups; ++g) { B.from[g] = c.groups[g].from; B.to[g] = c.groups[g].to; }
+    for (uint32_t m = 0; m < c.n_modes; ++m) {
+        B.n_roles[m] = c.modes[m].n_roles;
+        for (uint32_t r = 0; r < c.modes[m].n_roles; ++r)
+            if (c.modes[m].role_quota[r]) B.quota_mask[m] |= 1u << r;
+    }
+    return B;
+}
+
+static ModeDev make_mode_dev(const mm_mode_config& mc)
+{
+    ModeDev M;
+    memset(&M, 0, sizeof(M));
+    M.team_size = mc.team_size;
+    M.teams = mc.teams;
+    M.window = mc.window;
+    M.eqmask = ((mc.flags & MM_MODE_REGION_FILTER) ? (0xFFu << 4) : 0u) |
+               ((mc.flags & MM_MODE_PARTY_FILTER) ? (0xFu << 12) : 0u);
+    M.n_roles = mc.n_roles;
+    M.L = mc.teams * mc.team_size;
+    for (uint32_t r = 0; r < mc.n_roles; ++r) M.quota[r] = mc.role_quota[r];
+    return M;
+}
+
+extern "C" void mm_engine_destroy(mm_engine* e)
+{
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(e->d_q_rating);
+    (void)hipFree(e->d_q_cons);
+    (void)hipFree(e->d_q_slot);
+    (void)hipFree(e->d_chains);
+    (void)hipFree(e->d_state);
+    (void)hipFree(e->d_released);
+    (void)hipFree(e->d_counters);
+    (void)hipFree(e->d_wave_hist);
+    (void)hipFree(e->d_in_rating);
+    (void)hipFree(e->d_in_cons);
+    (void)hipFree(e->d_in_group);
+    (void)hipFree(e->d_in_slot);
+    (void)hipFree(e->d_out_slots);
+    (void)hipFree(e->d_out_score);
+    (void)hipFree(e->d_out_pass);
+    if (e->h_chains) (void)hipHostFree(e->h_chains);
+    if (e->h_counters) (void)hipHostFree(e->h_counters);
+    for (int i = 0; i < 4; ++i)
+        if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int engine_reset_device(mm_engine* e)
+{
+    const uint32_t words = e->n_chains * (uint32_t)(sizeof(ChainDev) / 4);
+    hipLaunchKernelGGL(k_reset, dim3((words + 255) / 256), dim3(256), 0, e->stream, e->n_chains, e->d_chains);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemsetAsync(e->d_state, 0, e->cfg.capacity, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_counters, 0, 2 * sizeof(uint32_t), e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return MM_OK;
+}
+
+extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
+{
+    if (!cfg || !out) return MM_ERR_INVALID_ARG;
+    *out = NULL;
+    int rc = cfg_validate(cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return MM_ERR_NO_DEVICE;
+    mm_engine* e = new (std::nothrow) mm_engine();
+    if (!e) return MM_ERR_OOM;
+    e->cfg = *cfg;
+    e->n_chains = cfg->n_modes * cfg->n_groups;
+    e->last_hip = 0;
+    e->next_slot = 0;
+    e->cancel_pending = 0;
+    e->r_n = 0;
+    e->r_L = 2;
+    e->in_cap = 0;
+    e->wave_hist_rows = 0;
+    const size_t cap = cfg->capacity;
+#define CREATE_CHK(call)                                                 \
+    do {                                                                 \
+        hipError_t _rc = (call);                                         \
+        if (_rc != hipSuccess) {                                         \
+            int code = _rc == hipErrorOutOfMemory ? MM_ERR_OOM : MM_ERR_HIP; \
+            mm_engine_destroy(e);                                        \
+            return code;                                                 \
+        }                                                                \
+    } while (0)
+    CREATE_CHK(hipSetDevice(cfg->device));
+    CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) CREATE_CHK(hipEventCreate(&e->ev[i]));
+    CREATE_CHK(hipMalloc((void**)&e->d_q_rating, e->n_chains * cap * sizeof(int32_t)));
+    CREATE_CHK(hipMalloc((void**)&e->d_q_cons, e->n_chains * cap * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&e->d_q_slot, e->n_chains * cap * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&e->d_chains, e->n_chains * sizeof(ChainDev)));
+    CREATE_CHK(hipMalloc((void**)&e->d_state, cap));
+    CREATE_CHK(hipMalloc((void**)&e->d_released, (cap + 64) * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&e->d_counters, 2 * sizeof(uint32_t)));
+    // emission logs: a group can emit at most (cap + lobby) / 2 lobbies of >= 2 players
+    e->out_slot_stride = (uint32_t)(cap + 64);
+    e->out_rec_stride = (uint32_t)(cap / 2 + 16);
+    CREATE_CHK(hipMalloc((void**)&e->d_out_slots, (size_t)cfg->n_groups * e->out_slot_stride * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&e->d_out_score, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(float)));
+    CREATE_CHK(hipMalloc((void**)&e->d_out_pass, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(uint32_t)));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_chains, e->n_chains * sizeof(ChainDev), hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault));
+#undef CREATE_CHK
+    e->h_state.assign(cap, MM_ST_FREE);
+    rc = engine_reset_device(e);
+    if (rc) { mm_engine_destroy(e); return rc; }
+    *out = e;
+    return MM_OK;
+}
+
+extern "C" int mm_reset(mm_engine* e)
+{
+    if (!e) return MM_ERR_INVALID_ARG;
+    std::fill(e->h_state.begin(), e->h_state.end(), (uint8_t)MM_ST_FREE);
+    e->next_slot = 0;
+    e->cancel_pending = 0;
+    e->r_n = 0;
+    return engine_reset_device(e);
+}
+
+static int ensure_staging(mm_engine* e, size_t n)
+{
+    if (n <= e->in_cap) return MM_OK;
+    size_t cap = e->in_cap ? e->in_cap : 4096;
+    while (cap < n) cap *= 2;
+    (void)hipFree(e->d_in_rating); e->d_in_rating = NULL;
+    (void)hipFree(e->d_in_cons); e->d_in_cons = NULL;
+    (void)hipFree(e->d_in_group); e->d_in_group = NULL;
+    (void)hipFree(e->d_in_slot); e->d_in_slot = NULL;
+    e->in_cap = 0;
+    HIPCHK(e, hipMalloc((void**)&e->d_in_rating, cap * sizeof(int32_t)));
+    HIPCHK(e, hipMalloc((void**)&e->d_in_cons, cap * sizeof(uint32_t)));
+    HIPCHK(e, hipMalloc((void**)&e->d_in_group, cap));
+    HIPCHK(e, hipMalloc((void**)&e->d_in_slot, cap * sizeof(uint32_t)));
+    e->in_cap = cap;
+    return MM_OK;
+}
+
+// Shared by both enqueue entry points; all pointers are device pointers.
+static int enqueue_device_impl(mm_engine* e, uint32_t n, const int32_t* d_rating, const uint32_t* d_cons,
+                               const uint8_t* d_group, uint32_t* d_out_slot, uint32_t* rejected, float* bucket_ms)
+{
+    const uint32_t blocks = (n + BK_CHUNK - 1) / BK_CHUNK;
+    const size_t rows = (size_t)blocks * BK_WAVES;
+    if (rows > e->wave_hist_rows) {
+        (void)hipFree(e->d_wave_hist);
+        e->d_wave_hist = NULL;
+        e->wave_hist_rows = 0;
+        HIPCHK(e, hipMalloc((void**)&e->d_wave_hist, rows * e->n_chains * sizeof(uint32_t)));
+        e->wave_hist_rows = rows;
+    }
+    const BucketCfg B = make_bucket_cfg(e->cfg);
+    const bool timing = (e->cfg.flags & MM_CFG_TIMING) != 0;
+    HIPCHK(e, hipMemsetAsync(e->d_counters + 1, 0, sizeof(uint32_t), e->stream));
+    if (timing) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
+    hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(BK_THREADS), 0, e->stream, n, d_rating, d_cons, d_group, B,
+                       e->n_chains, e->d_wave_hist, e->d_counters + 1);
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(BK_THREADS), 0, e->stream, (uint32_t)rows, e->n_chains,
+                       e->d_wave_hist, e->d_chains, e->cfg.capacity);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(BK_THREADS), 0, e->stream, n, d_rating, d_cons, d_group, B,
+                       e->n_chains, e->d_wave_hist, e->next_slot, e->d_q_rating, e->d_q_cons, e->d_q_slot,
+                       e->d_state, d_out_slot);
+    HIPCHK(e, hipGetLastError());
+    if (timing) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->h_counters + 1, e->d_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    *rejected = e->h_counters[1];
+    *bucket_ms = 0.f;
+    if (timing) HIPCHK(e, hipEventElapsedTime(bucket_ms, e->ev[0], e->ev[1]));
+    return MM_OK;
+}
+
+static int ring_range_free(const mm_engine* e, uint32_t n)
+{
+    const uint32_t cap = e->cfg.capacity;
+    if (n > cap) return 0;
+    const uint32_t a = e->next_slot;
+    const uint32_t n1 = n < cap - a ? n : cap - a;
+    if (n1 && memchr(&e->h_state[a], MM_ST_LIVE, n1)) return 0;
+    if (n1 && memchr(&e->h_state[a], MM_ST_CANCELLED, n1)) return 0;
+    if (n > n1) {
+        if (memchr(&e->h_state[0], MM_ST_LIVE, n - n1)) return 0;
+        if (memchr(&e->h_state[0], MM_ST_CANCELLED, n - n1)) return 0;
+    }
+    return 1;
+}
+
+extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const uint32_t* cons,
+                          const uint8_t* group, uint32_t* out_slot, mm_enqueue_stats* st)
+{
+    if (!e || (n && (!rating || !cons))) return MM_ERR_INVALID_ARG;
+    const double t0 = host_now_ms();
+    if (st) memset(st, 0, sizeof(*st));
+    if (n == 0) return MM_OK;
+    if (!ring_range_free(e, n)) return MM_ERR_FULL;
+    if (group)
+        for (uint32_t i = 0; i < n; ++i)
+            if (group[i] >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
+    int rc = ensure_staging(e, n);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->d_in_rating, rating, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_in_cons, cons, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    if (group) HIPCHK(e, hipMemcpyAsync(e->d_in_group, group, n, hipMemcpyHostToDevice, e->stream));
+    uint32_t rejected = 0;
+    float bms = 0.f;
+    rc = enqueue_device_impl(e, n, e->d_in_rating, e->d_in_cons, group ? e->d_in_group : NULL, e->d_in_slot,
+                             &rejected, &bms);
+    if (rc) return rc;
+    std::vector<uint32_t> tmp;
+    uint32_t* slots = out_slot;
+    if (!slots) { tmp.resize(n); slots = tmp.data(); }
+    HIPCHK(e, hipMemcpy(slots, e->d_in_slot, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+        if (slots[i] != MM_NO_SLOT) e->h_state[slots[i]] = MM_ST_LIVE;
+    e->next_slot = (uint32_t)(((unsigned long long)e->next_slot + n) % e->cfg.capacity);
+    if (st) {
+        st->accepted = n - rejected;
+        st->rejected = rejected;
+        st->bucket_ms = bms;
+        st->total_ms = (float)(host_now_ms() - t0);
+    }
+    return MM_OK;
+}
+
+extern "C" int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rating, const uint32_t* d_cons,
+                                 uint32_t* first_slot, mm_enqueue_stats* st)
+{
+    if (!e || (n && (!d_rating || !d_cons))) return MM_ERR_INVALID_ARG;
+    const double t0 = host_now_ms();
+    if (st) memset(st, 0, sizeof(*st));
+    if (first_slot) *first_slot = e->next_slot;
+    if (n == 0) return MM_OK;
+    if (!ring_range_free(e, n)) return MM_ERR_FULL;
+    uint32_t rejected = 0;
+    float bms = 0.f;
+    int rc = enqueue_device_impl(e, n, d_rating, d_cons, NULL, NULL, &rejected, &bms);
+    if (rc) return rc;
+    // the host cannot see which players were rejected: the whole range stays reserved
+    const uint32_t cap = e->cfg.capacity;
+    const uint32_t a = e->next_slot, n1 = n < cap - a ? n : cap - a;
+    memset(&e->h_state[a], MM_ST_LIVE, n1);
+    if (n > n1) memset(&e->h_state[0], MM_ST_LIVE, n - n1);
+    e->next_slot = (uint32_t)(((unsigned long long)a + n) % cap);
+    if (st) {
+        st->accepted = n - rejected;
+        st->rejected = rejected;
+        st->bucket_ms = bms;
+        st->total_ms = (float)(host_now_ms() - t0);
+    }
+    return MM_OK;
+}
+
+extern "C" int mm_cancel(mm_engine* e, uint32_t n, const uint32_t* slot)
+{
+    if (!e || (n && !slot)) return MM_ERR_INVALID_ARG;
+    std::vector<uint32_t> live;
+    live.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (slot[i] >= e->cfg.capacity) continue;
+        if (e->h_state[slot[i]] == MM_ST_LIVE) {
+            e->h_state[slot[i]] = MM_ST_CANCELLED;
+            live.push_back(slot[i]);
+        }
+    }
+    if (live.empty()) return MM_OK;
+    int rc = ensure_staging(e, live.size());
+    if (rc) return rc;
+    const uint32_t k = (uint32_t)live.size();
+    HIPCHK(e, hipMemcpyAsync(e->d_in_slot, live.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_cancel, dim3((k + 255) / 256), dim3(256), 0, e->stream, k, e->d_in_slot, e->d_state);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));   // `live` must outlive the copy
+    e->cancel_pending += k;
+    return MM_OK;
+}
+
+extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats)
+{
+    if (!e || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
+    const double t0 = host_now_ms();
+    const mm_config& cfg = e->cfg;
+    const uint32_t G = cfg.n_groups;
+    const ModeDev M = make_mode_dev(cfg.modes[mode]);
+    const bool timing = (cfg.flags & MM_CFG_TIMING) != 0;
+    const bool purge = e->cancel_pending > 0;
+    e->r_n = 0;
+    e->r_L = M.L;
+
+    HIPCHK(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t), e->stream));
+    if (timing) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
+    if (purge) {
+        hipLaunchKernelGGL(k_purge, dim3(G), dim3(WK_THREADS), 0, e->stream, mode, G, cfg.capacity, e->d_chains,
+                           e->d_q_rating, e->d_q_cons, e->d_q_slot, e->d_state, e->d_released, e->d_counters);
+        HIPCHK(e, hipGetLastError());
+    }
+    if (timing) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
+    WalkParams P;
+    memset(&P, 0, sizeof(P));
+    P.mode = mode;
+    P.n_groups = G;
+    P.capacity = cfg.capacity;
+    P.purge = purge ? 1u : 0u;
+    P.out_cap = (cfg.capacity + MM_MAX_LOBBY) / M.L + 1u;   // lobbies a group can emit at most
+    P.out_slot_stride = e->out_slot_stride;
+    P.out_rec_stride = e->out_rec_stride;
+    P.max_passes = 0x7FFFFFFFu;
+    P.M = M;
+    P.chains = e->d_chains;
+    P.q_rating = e->d_q_rating;
+    P.q_cons = e->d_q_cons;
+    P.q_slot = e->d_q_slot;
+    P.state = e->d_state;
+    P.released = e->d_released;
+    P.n_released = e->d_counters;
+    P.out_slots = e->d_out_slots;
+    P.out_score = e->d_out_score;
+    P.out_pass = e->d_out_pass;
+    hipLaunchKernelGGL(k_walk, dim3(G), dim3(WK_THREADS), 0, e->stream, P);
+    HIPCHK(e, hipGetLastError());
+    if (timing) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->h_chains, e->d_chains, e->n_chains * sizeof(ChainDev), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const double t_copy0 = host_now_ms();
+
+    uint32_t total = 0, after = 0, before = 0, pmax = 0, errf = 0;
+    unsigned long long pairs = 0, scanned = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        const ChainDev& c = e->h_chains[mode * G + g];
+        total += c.n_out;
+        after += c.len + c.lobby.n;
+        before += c.before;
+        pairs += c.pairs;
+        scanned += c.scanned;
+        errf |= c.err;
+        if (c.passes > pmax) pmax = c.passes;
+    }
+    if (errf) return MM_ERR_INTERNAL;
+    e->r_slots.resize((size_t)total * M.L);
+    e->r_score.resize(total);
+    e->r_pass.resize(total);
+    e->r_group.resize(total);
+    uint32_t k = 0;
+    for (uint32_t g = 0; g < G; ++g) {   // group-major emission order
+        const uint32_t ng = e->h_chains[mode * G + g].n_out;
+        if (!ng) continue;
+        HIPCHK(e, hipMemcpyAsync(&e->r_slots[(size_t)k * M.L], e->d_out_slots + (size_t)g * e->out_slot_stride,
+                                 (size_t)ng * M.L * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(&e->r_score[k], e->d_out_score + (size_t)g * e->out_rec_stride, ng * sizeof(float),
+                                 hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(&e->r_pass[k], e->d_out_pass + (size_t)g * e->out_rec_stride, ng * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, e->stream));
+        for (uint32_t i = 0; i < ng; ++i) e->r_group[k + i] = g;
+        k += ng;
+    }
+    const uint32_t nrel = e->h_counters[0];
+    e->r_released.resize(nrel);
+    if (nrel)
+        HIPCHK(e, hipMemcpyAsync(e->r_released.data(), e->d_released, nrel * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    // ActiveUser.remove_user for matched players (game-lobby/worker.ex:73-103) and the
+    // slots the liveness filter released
+    for (size_t i = 0; i < e->r_slots.size(); ++i) e->h_state[e->r_slots[i]] = MM_ST_FREE;
+    for (uint32_t i = 0; i < nrel; ++i) e->h_state[e->r_released[i]] = MM_ST_FREE;
+    e->cancel_pending = e->cancel_pending >= nrel ? e->cancel_pending - nrel : 0;
+    e->r_n = total;
+    if (n_matches) *n_matches = total;
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->pool_before = before;
+        stats->pool_after = after;
+        stats->matches = total;
+        stats->players_matched = total * M.L;
+        stats->passes_max = pmax;
+        stats->chains = G;
+        stats->pairs = pairs;
+        stats->scanned = scanned;
+        if (timing) {
+            (void)hipEventElapsedTime(&stats->filter_ms, e->ev[0], e->ev[1]);
+            (void)hipEventElapsedTime(&stats->walk_ms, e->ev[1], e->ev[2]);
+        }
+        const double t1 = host_now_ms();
+        stats->copy_ms = (float)(t1 - t_copy0);
+        stats->total_ms = (float)(t1 - t0);
+    }
+    return MM_OK;
+}
+
+extern "C" int mm_matches(mm_engine* e, uint32_t first, uint32_t count, uint32_t* slots, float* score,
+                          uint32_t* group, uint32_t* pass)
+{
+    if (!e) return MM_ERR_INVALID_ARG;
+    if (first > e->r_n || count > e->r_n - first) return MM_ERR_RANGE;
+    if (count == 0) return MM_OK;
+    if (slots) memcpy(slots, &e->r_slots[(size_t)first * e->r_L], (size_t)count * e->r_L * sizeof(uint32_t));
+    if (score) memcpy(score, &e->r_score[first], count * sizeof(float));
+    if (group) memcpy(group, &e->r_group[first], count * sizeof(uint32_t));
+    if (pass) memcpy(pass, &e->r_pass[first], count * sizeof(uint32_t));
+    return MM_OK;
+}
+
+static int fetch_chains(mm_engine* e)
+{
+    HIPCHK(e, hipMemcpyAsync(e->h_chains, e->d_chains, e->n_chains * sizeof(ChainDev), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return MM_OK;
+}
+
+extern "C" int mm_queue_depth(mm_engine* e, uint32_t mode, uint32_t* per_group)
+{
+    if (!e || !per_group || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
+    int rc = fetch_chains(e);
+    if (rc) return rc;
+    for (uint32_t g = 0; g < e->cfg.n_groups; ++g) per_group[g] = e->h_chains[mode * e->cfg.n_groups + g].len;
+    return MM_OK;
+}
+
+extern "C" int mm_lobby_state(mm_engine* e, uint32_t mode, uint32_t group, uint32_t* n, uint32_t* slots,
+                              uint8_t* teams)
+{
+    if (!e || !n || mode >= e->cfg.n_modes || group >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
+    int rc = fetch_chains(e);
+    if (rc) return rc;
+    const LobbyDev& lb = e->h_chains[mode * e->cfg.n_groups + group].lobby;
+    uint32_t k = 0;
+    for (uint32_t t = 0; t < e->cfg.modes[mode].teams; ++t)
+        for (uint32_t j = 0; j < lb.cnt[t] && j < 8; ++j) {
+            if (slots) slots[k] = lb.slot[t][j];
+            if (teams) teams[k] = (uint8_t)t;
+            ++k;
+        }
+    *n = k;
+    return MM_OK;
+}
+
+extern "C" int mm_last_hip_error(const mm_engine* e) { return e ? e->last_hip : 0; }

@@ -1,0 +1,25 @@
+"""Loads tests/emu/libmm_engine_emu.so — the UNMODIFIED engine source compiled against the
+fiber shim (tests/emu/).  Test infrastructure only: exercises kernel control logic on a box
+without a GPU.  The product package never loads this library."""
+import ctypes as C
+import os
+import subprocess
+
+from microservice_matchmaking_amd._abi import EngineBase, bind
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+def load():
+    subprocess.check_call(["make", "-C", _DIR, "--no-print-directory"], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(_DIR, "libmm_engine_emu.so"))
+    return bind(lib, "mm_")
+
+
+class EmuEngine(EngineBase):
+    _prefix = "mm_"
+
+    def __init__(self, cfg):
+        if EmuEngine._lib is None:
+            EmuEngine._lib = load()
+        super().__init__(cfg)
