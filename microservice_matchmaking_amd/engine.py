@@ -29,6 +29,13 @@ def load_library():
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C microservice_matchmaking_amd/csrc` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
+        try:
+            # torch ships its own libamdhip64.so.7; importing it first makes this process use
+            # ONE HIP runtime (ours resolves to the already-loaded SONAME), so torch tensors'
+            # device pointers and our stream live in the same runtime.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         bind(lib, "mm_")
         lib.mm_abi_version.restype = C.c_uint32

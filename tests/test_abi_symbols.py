@@ -1,0 +1,94 @@
+"""The C-ABI library loads and exports every symbol include/mm_engine.h declares
+(no compute calls: there is no GPU in the `-m "not gpu"` environment)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from microservice_matchmaking_amd import MMError, make_config, mode_1v1
+from microservice_matchmaking_amd._abi import MMConfig, MMEnqueueStats, MMModeConfig, MMStats
+from microservice_matchmaking_amd.engine import LIB_PATH, load_library
+
+HEADER = os.path.join(ROOT, "include", "mm_engine.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mm_[a-z_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.check_call(["make", "-C", os.path.dirname(LIB_PATH), "--no-print-directory"],
+                          stdout=subprocess.DEVNULL)
+    return load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 15, names
+    for n in names:
+        assert hasattr(lib, n), "libmm_engine.so does not export %s" % n
+
+
+def test_oracle_exports_the_mirrored_abi(oracle_cls):
+    from oracle.oracle import load
+    olib = load()
+    for n in declared_functions():
+        if n in ("mm_abi_version", "mm_strerror", "mm_config_default", "mm_enqueue_device",
+                 "mm_last_hip_error"):
+            continue
+        assert hasattr(olib, "mo_" + n[3:]), n
+
+
+def test_struct_layouts_match_the_header(lib):
+    # sizes the C compiler gives the header's structs, via a tiny probe program
+    probe = r'''
+#include <stdio.h>
+#include "mm_engine.h"
+int main(void){printf("%zu %zu %zu %zu\n", sizeof(mm_config), sizeof(mm_mode_config), sizeof(mm_stats), sizeof(mm_enqueue_stats));return 0;}
+'''
+    exe = "/tmp/mm_abi_probe"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe],
+                   input=probe.encode(), check=True)
+    sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert sizes == [C.sizeof(MMConfig), C.sizeof(MMModeConfig), C.sizeof(MMStats), C.sizeof(MMEnqueueStats)]
+
+
+def test_library_level_calls_need_no_gpu(lib):
+    assert lib.mm_abi_version() == 1
+    assert lib.mm_strerror(0) == b"ok"
+    assert b"device" in lib.mm_strerror(-2)
+    cfg = MMConfig()
+    assert lib.mm_config_default(C.byref(cfg)) == 0
+    assert cfg.n_groups == 7 and cfg.default_group == 4 and cfg.groups[6].to == 5000
+    g = C.c_uint32()
+    for rating, want in ((1499, 0), (1500, 1), (5001, 4), (1499.5, 4), (float("nan"), 4)):
+        assert lib.mm_find_rating_group(C.byref(cfg), rating, C.byref(g)) == 0
+        assert g.value == want
+
+
+def test_bad_config_is_rejected_before_touching_a_device(lib):
+    cfg = make_config([mode_1v1()])
+    cfg.abi_version = 99
+    h = C.c_void_p()
+    assert lib.mm_engine_create(C.byref(cfg), C.byref(h)) == -7          # MM_ERR_ABI
+    cfg = make_config([mode_1v1()])
+    cfg.modes[0].role_quota[0] = 2                                        # sums to 2 != team_size
+    assert lib.mm_engine_create(C.byref(cfg), C.byref(h)) == -1
+    assert lib.mm_engine_create(None, C.byref(h)) == -1
+    lib.mm_engine_destroy(None)                                           # NULL-safe
+
+
+def test_product_fails_loudly_without_a_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from microservice_matchmaking_amd import Engine
+    with pytest.raises(MMError) as ei:
+        Engine(make_config([mode_1v1()]))
+    assert ei.value.status == -2   # MM_ERR_NO_DEVICE — never a silent CPU path
