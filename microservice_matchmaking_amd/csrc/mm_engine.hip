@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -368,6 +369,9 @@ __global__ __launch_bounds__(256) void k_reset(uint32_t n_chains, ChainDev* __re
 // the walk kernel: Search.Worker.consume/5 to quiescence, one workgroup per chain
 // ------------------------------------------------------------------------------------
 
+struct PairChain;
+static __device__ __forceinline__ bool pair_chain_is_fast(const struct PairChain* pc, uint32_t g);
+
 struct WalkParams {
     uint32_t mode, n_groups, capacity, purge;
     uint32_t out_cap;          // lobbies per group the out_* arrays can hold
@@ -385,6 +389,7 @@ struct WalkParams {
     uint32_t* out_slots;       // [n_groups][out_slot_stride], team-ordered slots, L per lobby
     float* out_score;          // [n_groups][out_rec_stride]
     uint32_t* out_pass;        // [n_groups][out_rec_stride]
+    const struct PairChain* pskip;   // chains the pair path (mm_pair.inc) walks this tick, or NULL
 };
 
 // Discipline for the LDS lobby inside wave 0: every lane may READ it between two
@@ -488,6 +493,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = blockIdx.x;
+    if (P.pskip && pair_chain_is_fast(P.pskip, g)) return;   // walked by the pair path
     const uint32_t c = P.mode * P.n_groups + g;
     const ModeDev& M = P.M;
     const size_t qo = (size_t)c * P.capacity;
@@ -712,6 +718,13 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
     }
 }
 
+#include "mm_pair.inc"
+
+static __device__ __forceinline__ bool pair_chain_is_fast(const struct PairChain* pc, uint32_t g)
+{
+    return pc[g].fast != 0u;
+}
+
 // ------------------------------------------------------------------------------------
 // host side: the C ABI
 // ------------------------------------------------------------------------------------
@@ -741,6 +754,18 @@ struct mm_engine {
     float* d_out_score;
     uint32_t* d_out_pass;
     uint32_t out_slot_stride, out_rec_stride;
+    // pair path (mm_pair.inc): per rating group, the ticked mode's chains
+    PairChain* d_pchains;
+    uint32_t* d_pk_key[2];
+    uint32_t* d_pk_oidx[2];
+    uint16_t* d_pk_nx16;
+    uint32_t* d_pk_bits;
+    uint32_t* d_pk_scratch;
+    uint32_t pk_bits_stride;
+    bool force_generic;        // MM_FORCE_GENERIC=1: always walk with k_walk (A/B testing)
+    bool pair_debug;           // MM_PAIR_DEBUG=1: print the pair path's diagnostics per tick
+    uint32_t pair_tune;        // MM_PAIR_TUNE: PairParams.tune
+    unsigned long long live_upper;   // upper bound of queued players (grid sizing)
     // host
     ChainDev* h_chains;        // pinned, n_chains
     uint32_t* h_counters;      // pinned, 2
@@ -891,6 +916,11 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_out_slots);
     (void)hipFree(e->d_out_score);
     (void)hipFree(e->d_out_pass);
+    (void)hipFree(e->d_pchains);
+    for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_key[b]); (void)hipFree(e->d_pk_oidx[b]); }
+    (void)hipFree(e->d_pk_nx16);
+    (void)hipFree(e->d_pk_bits);
+    (void)hipFree(e->d_pk_scratch);
     if (e->h_chains) (void)hipHostFree(e->h_chains);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (int i = 0; i < 4; ++i)
@@ -930,6 +960,15 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
     e->r_L = 2;
     e->in_cap = 0;
     e->wave_hist_rows = 0;
+    e->live_upper = 0;
+    {
+        const char* fg = getenv("MM_FORCE_GENERIC");
+        e->force_generic = fg && fg[0] == '1';
+        const char* pd = getenv("MM_PAIR_DEBUG");
+        e->pair_debug = pd && pd[0] == '1';
+        const char* pt = getenv("MM_PAIR_TUNE");
+        e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
+    }
     const size_t cap = cfg->capacity;
 #define CREATE_CHK(call)                                                 \
     do {                                                                 \
@@ -956,6 +995,19 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
     CREATE_CHK(hipMalloc((void**)&e->d_out_slots, (size_t)cfg->n_groups * e->out_slot_stride * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&e->d_out_score, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(float)));
     CREATE_CHK(hipMalloc((void**)&e->d_out_pass, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(uint32_t)));
+    {
+        const size_t gc = (size_t)cfg->n_groups * cap;
+        e->pk_bits_stride = (uint32_t)(cap / 32 + 4);
+        CREATE_CHK(hipMalloc((void**)&e->d_pchains, cfg->n_groups * sizeof(PairChain)));
+        for (int b = 0; b < 2; ++b) {
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_key[b], gc * sizeof(uint32_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_oidx[b], gc * sizeof(uint32_t)));
+        }
+        CREATE_CHK(hipMalloc((void**)&e->d_pk_nx16, gc * sizeof(uint16_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_pk_bits, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_pk_scratch, gc * sizeof(uint32_t)));
+        CREATE_CHK(hipMemsetAsync(e->d_pchains, 0, cfg->n_groups * sizeof(PairChain), e->stream));
+    }
     CREATE_CHK(hipHostMalloc((void**)&e->h_chains, e->n_chains * sizeof(ChainDev), hipHostMallocDefault));
     CREATE_CHK(hipHostMalloc((void**)&e->h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault));
 #undef CREATE_CHK
@@ -973,6 +1025,7 @@ extern "C" int mm_reset(mm_engine* e)
     e->next_slot = 0;
     e->cancel_pending = 0;
     e->r_n = 0;
+    e->live_upper = 0;
     return engine_reset_device(e);
 }
 
@@ -1071,6 +1124,7 @@ extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const
     for (uint32_t i = 0; i < n; ++i)
         if (slots[i] != MM_NO_SLOT) e->h_state[slots[i]] = MM_ST_LIVE;
     e->next_slot = (uint32_t)(((unsigned long long)e->next_slot + n) % e->cfg.capacity);
+    e->live_upper += n - rejected;
     if (st) {
         st->accepted = n - rejected;
         st->rejected = rejected;
@@ -1099,6 +1153,7 @@ extern "C" int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rati
     memset(&e->h_state[a], MM_ST_LIVE, n1);
     if (n > n1) memset(&e->h_state[0], MM_ST_LIVE, n - n1);
     e->next_slot = (uint32_t)(((unsigned long long)a + n) % cap);
+    e->live_upper += n - rejected;
     if (st) {
         st->accepted = n - rejected;
         st->rejected = rejected;
@@ -1132,6 +1187,46 @@ extern "C" int mm_cancel(mm_engine* e, uint32_t n, const uint32_t* slot)
     return MM_OK;
 }
 
+// The pair path (mm_pair.inc) for every chain of `mode` it is eligible for; the others are
+// left to k_walk (PairChain.fast == 0).  All launches are asynchronous on the engine stream.
+static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
+{
+    const mm_config& cfg = e->cfg;
+    const uint32_t G = cfg.n_groups;
+    PairParams P;
+    memset(&P, 0, sizeof(P));
+    P.mode = mode;
+    P.n_groups = G;
+    P.capacity = cfg.capacity;
+    P.window = M.window > 0xFFFFFu ? 0xFFFFFu : M.window;   // rating span of a fast chain < 2^20
+    P.eqmask = M.eqmask;
+    P.out_slot_stride = e->out_slot_stride;
+    P.out_rec_stride = e->out_rec_stride;
+    P.bits_stride = e->pk_bits_stride;
+    P.tune = e->pair_tune;
+    P.chains = e->d_chains;
+    P.pchains = e->d_pchains;
+    P.q_rating = e->d_q_rating;
+    P.q_cons = e->d_q_cons;
+    P.q_slot = e->d_q_slot;
+    for (int b = 0; b < 2; ++b) { P.key[b] = e->d_pk_key[b]; P.oidx[b] = e->d_pk_oidx[b]; }
+    P.nx16 = e->d_pk_nx16;
+    P.bits = e->d_pk_bits;
+    P.scratch = e->d_pk_scratch;
+    P.out_slots = e->d_out_slots;
+    P.out_score = e->d_out_score;
+    P.out_pass = e->d_out_pass;
+    const unsigned long long bound64 = e->live_upper < cfg.capacity ? e->live_upper : cfg.capacity;
+    const uint32_t bound = (uint32_t)bound64;
+    hipLaunchKernelGGL(kp_init, dim3(G), dim3(1024), 0, e->stream, P, (uint32_t)PL_MAX);
+    hipLaunchKernelGGL(kp_pack, dim3((bound + 32u + 1023u) / 1024u, G), dim3(1024), 0, e->stream, P);
+    hipLaunchKernelGGL(kp_nx_init, dim3((bound + NXI_SEG - 1u) / NXI_SEG + 1u, G), dim3(NXI_THREADS), 0, e->stream, P);
+    hipLaunchKernelGGL(kp_late, dim3(G), dim3(PL_THREADS), 0, e->stream, P);
+    hipLaunchKernelGGL(kp_finish, dim3(G), dim3(1024), 0, e->stream, P);
+    HIPCHK(e, hipGetLastError());
+    return MM_OK;
+}
+
 extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats)
 {
     if (!e || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
@@ -1152,6 +1247,11 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
         HIPCHK(e, hipGetLastError());
     }
     if (timing) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
+    const bool use_pair = M.team_size == 1u && M.teams == 2u && !purge && !e->force_generic;
+    if (use_pair) {
+        int prc = pair_walk(e, mode, M);
+        if (prc) return prc;
+    }
     WalkParams P;
     memset(&P, 0, sizeof(P));
     P.mode = mode;
@@ -1173,6 +1273,7 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
     P.out_slots = e->d_out_slots;
     P.out_score = e->d_out_score;
     P.out_pass = e->d_out_pass;
+    P.pskip = use_pair ? e->d_pchains : NULL;
     hipLaunchKernelGGL(k_walk, dim3(G), dim3(WK_THREADS), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
     if (timing) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
@@ -1180,6 +1281,14 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
     HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     const double t_copy0 = host_now_ms();
+    if (use_pair && e->pair_debug) {
+        std::vector<PairChain> hp(G);
+        HIPCHK(e, hipMemcpy(hp.data(), e->d_pchains, G * sizeof(PairChain), hipMemcpyDeviceToHost));
+        for (uint32_t g = 0; g < G; ++g)
+            fprintf(stderr, "[mm-pair] g%u fast %u m %u qlen %u passes %u out %u | stale %u inv %u slowsucc %u compact %u fixed(w1) %u | chase clk %u wall(100MHz) %u wrapscan clk %u\n",
+                    g, hp[g].fast, hp[g].m, hp[g].qlen, hp[g].passes, hp[g].n_out, hp[g].dbg[0], hp[g].dbg[1],
+                    hp[g].dbg[2], hp[g].dbg[3], hp[g].dbg[4], hp[g].dbg[5], hp[g].dbg[6], hp[g].dbg[7]);
+    }
 
     uint32_t total = 0, after = 0, before = 0, pmax = 0, errf = 0;
     unsigned long long pairs = 0, scanned = 0;
@@ -1221,6 +1330,10 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
     for (size_t i = 0; i < e->r_slots.size(); ++i) e->h_state[e->r_slots[i]] = MM_ST_FREE;
     for (uint32_t i = 0; i < nrel; ++i) e->h_state[e->r_released[i]] = MM_ST_FREE;
     e->cancel_pending = e->cancel_pending >= nrel ? e->cancel_pending - nrel : 0;
+    {
+        const unsigned long long gone = (unsigned long long)total * M.L + nrel;
+        e->live_upper = e->live_upper >= gone ? e->live_upper - gone : 0;
+    }
     e->r_n = total;
     if (n_matches) *n_matches = total;
     if (stats) {

@@ -157,10 +157,11 @@ void emu_launch(emu_dim3 grid, emu_dim3 block, const std::function<void()>& body
     g_body = &body;
     gridDim = grid;
     blockDim = block;
-    for (unsigned b = 0; b < grid.x; ++b) {
-        blockIdx = emu_dim3(b, 0, 0);
-        run_block(block.x);
-    }
+    for (unsigned by = 0; by < grid.y; ++by)
+        for (unsigned b = 0; b < grid.x; ++b) {
+            blockIdx = emu_dim3(b, by, 0);
+            run_block(block.x);
+        }
     g_body = nullptr;
 }
 

@@ -84,14 +84,28 @@ static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
 
 /* wave_sync() of the engine: a fence is a no-op here, the wave barrier is a rendezvous */
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)__ballot(1))
+/* priorities do not exist here; a sleep must be a yield point or a polling wave would spin forever */
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_readfirstlane(v) (v)
+static inline long long clock64(void) { return 0; }
+static inline long long wall_clock64(void) { return 0; }
+/* relaxed workgroup-scope atomics: plain accesses through a volatile lvalue */
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __hip_atomic_load(p, order, scope) (*(const volatile __typeof__(*(p))*)(p))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(volatile __typeof__(*(p))*)(p) = (v)))
+#define __builtin_amdgcn_readlane(v, l) emu_shfl_i32((v), (l))
+#define __builtin_amdgcn_s_sleep(n) ((void)__ballot(1))
 
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 
 void emu_launch(emu_dim3 grid, emu_dim3 block, const std::function<void()>& body);
 
