@@ -758,10 +758,14 @@ struct mm_engine {
     PairChain* d_pchains;
     uint32_t* d_pk_key[2];
     uint32_t* d_pk_oidx[2];
-    uint16_t* d_pk_nx16;
-    uint32_t* d_pk_bits;
+    uint16_t* d_pk_nx16[2];
+    uint32_t* d_pk_bits[2];
     uint32_t* d_pk_scratch;
-    uint32_t pk_bits_stride;
+    uint16_t* d_pk_wpre;
+    uint32_t* d_pk_tilectl;
+    PairChain* h_pchains;      // pinned
+    uint32_t pk_bits_stride, pk_max_tiles;
+    uint32_t pair_batch;       // MM_PAIR_BATCH: tiled rounds launched per host look at the chains
     bool force_generic;        // MM_FORCE_GENERIC=1: always walk with k_walk (A/B testing)
     bool pair_debug;           // MM_PAIR_DEBUG=1: print the pair path's diagnostics per tick
     uint32_t pair_tune;        // MM_PAIR_TUNE: PairParams.tune
@@ -917,10 +921,14 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_out_score);
     (void)hipFree(e->d_out_pass);
     (void)hipFree(e->d_pchains);
-    for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_key[b]); (void)hipFree(e->d_pk_oidx[b]); }
-    (void)hipFree(e->d_pk_nx16);
-    (void)hipFree(e->d_pk_bits);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(e->d_pk_key[b]); (void)hipFree(e->d_pk_oidx[b]);
+        (void)hipFree(e->d_pk_nx16[b]); (void)hipFree(e->d_pk_bits[b]);
+    }
     (void)hipFree(e->d_pk_scratch);
+    (void)hipFree(e->d_pk_wpre);
+    (void)hipFree(e->d_pk_tilectl);
+    if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_chains) (void)hipHostFree(e->h_chains);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (int i = 0; i < 4; ++i)
@@ -968,6 +976,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         e->pair_debug = pd && pd[0] == '1';
         const char* pt = getenv("MM_PAIR_TUNE");
         e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
+        const char* pb = getenv("MM_PAIR_BATCH");
+        e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 8u;
+        if (e->pair_batch < 1u) e->pair_batch = 1u;
     }
     const size_t cap = cfg->capacity;
 #define CREATE_CHK(call)                                                 \
@@ -999,13 +1010,17 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         const size_t gc = (size_t)cfg->n_groups * cap;
         e->pk_bits_stride = (uint32_t)(cap / 32 + 4);
         CREATE_CHK(hipMalloc((void**)&e->d_pchains, cfg->n_groups * sizeof(PairChain)));
+        e->pk_max_tiles = (uint32_t)(cap / PK_T + 2);
         for (int b = 0; b < 2; ++b) {
             CREATE_CHK(hipMalloc((void**)&e->d_pk_key[b], gc * sizeof(uint32_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_oidx[b], gc * sizeof(uint32_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_nx16[b], gc * sizeof(uint16_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_bits[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
         }
-        CREATE_CHK(hipMalloc((void**)&e->d_pk_nx16, gc * sizeof(uint16_t)));
-        CREATE_CHK(hipMalloc((void**)&e->d_pk_bits, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_pk_scratch, gc * sizeof(uint32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
+        CREATE_CHK(hipHostMalloc((void**)&e->h_pchains, cfg->n_groups * sizeof(PairChain), hipHostMallocDefault));
         CREATE_CHK(hipMemsetAsync(e->d_pchains, 0, cfg->n_groups * sizeof(PairChain), e->stream));
     }
     CREATE_CHK(hipHostMalloc((void**)&e->h_chains, e->n_chains * sizeof(ChainDev), hipHostMallocDefault));
@@ -1209,18 +1224,57 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
     P.q_rating = e->d_q_rating;
     P.q_cons = e->d_q_cons;
     P.q_slot = e->d_q_slot;
-    for (int b = 0; b < 2; ++b) { P.key[b] = e->d_pk_key[b]; P.oidx[b] = e->d_pk_oidx[b]; }
-    P.nx16 = e->d_pk_nx16;
-    P.bits = e->d_pk_bits;
+    for (int b = 0; b < 2; ++b) {
+        P.key[b] = e->d_pk_key[b]; P.oidx[b] = e->d_pk_oidx[b];
+        P.nx16[b] = e->d_pk_nx16[b]; P.bits[b] = e->d_pk_bits[b];
+    }
     P.scratch = e->d_pk_scratch;
+    P.wpre = e->d_pk_wpre;
+    P.tilectl = e->d_pk_tilectl;
+    P.max_tiles = e->pk_max_tiles;
     P.out_slots = e->d_out_slots;
     P.out_score = e->d_out_score;
     P.out_pass = e->d_out_pass;
     const unsigned long long bound64 = e->live_upper < cfg.capacity ? e->live_upper : cfg.capacity;
     const uint32_t bound = (uint32_t)bound64;
-    hipLaunchKernelGGL(kp_init, dim3(G), dim3(1024), 0, e->stream, P, (uint32_t)PL_MAX);
+    hipLaunchKernelGGL(kp_init, dim3(G), dim3(1024), 0, e->stream, P, cfg.capacity);
     hipLaunchKernelGGL(kp_pack, dim3((bound + 32u + 1023u) / 1024u, G), dim3(1024), 0, e->stream, P);
     hipLaunchKernelGGL(kp_nx_init, dim3((bound + NXI_SEG - 1u) / NXI_SEG + 1u, G), dim3(NXI_THREADS), 0, e->stream, P);
+    HIPCHK(e, hipGetLastError());
+    // ---- tiled rounds for the chains that do not fit one workgroup's LDS ----
+    if (bound > PL_MAX) {
+        uint32_t tiles = (bound + PK_T - 1u) / PK_T + 1u;
+        if (tiles > e->pk_max_tiles) tiles = e->pk_max_tiles;
+        for (;;) {
+            HIPCHK(e, hipMemcpyAsync(e->h_pchains, e->d_pchains, G * sizeof(PairChain), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            bool tiled = false, compact = false;
+            uint32_t longest = 0;
+            for (uint32_t g = 0; g < G; ++g) {
+                const PairChain& pc = e->h_pchains[g];
+                if (!pc.fast || pc.stage != PS_TILED) continue;
+                tiled = true;
+                compact |= pc.want_compact != 0;
+                longest = pc.m > longest ? pc.m : longest;
+            }
+            if (!tiled) break;
+            tiles = (longest + PK_T - 1u) / PK_T;
+            if (compact) {
+                hipLaunchKernelGGL(kc_words, dim3(tiles, G), dim3(256), 0, e->stream, P);
+                hipLaunchKernelGGL(kc_plan, dim3(G), dim3(1024), 0, e->stream, P);
+                hipLaunchKernelGGL(kc_scatter, dim3(tiles, G), dim3(1024), 0, e->stream, P);
+                hipLaunchKernelGGL(kc_commit, dim3(G), dim3(1024), 0, e->stream, P);
+                HIPCHK(e, hipGetLastError());
+                continue;                       // look at the new lengths before the next batch
+            }
+            for (uint32_t r = 0; r < e->pair_batch; ++r) {
+                hipLaunchKernelGGL(kp_tile_prep, dim3(tiles, G), dim3(PT_THREADS), 0, e->stream, P);
+                hipLaunchKernelGGL(kp_route, dim3(G), dim3(PR_THREADS), 0, e->stream, P);
+                hipLaunchKernelGGL(kp_tile_apply, dim3(tiles, G), dim3(PA_THREADS), 0, e->stream, P);
+            }
+            HIPCHK(e, hipGetLastError());
+        }
+    }
     hipLaunchKernelGGL(kp_late, dim3(G), dim3(PL_THREADS), 0, e->stream, P);
     hipLaunchKernelGGL(kp_finish, dim3(G), dim3(1024), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
@@ -1285,8 +1339,8 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
         std::vector<PairChain> hp(G);
         HIPCHK(e, hipMemcpy(hp.data(), e->d_pchains, G * sizeof(PairChain), hipMemcpyDeviceToHost));
         for (uint32_t g = 0; g < G; ++g)
-            fprintf(stderr, "[mm-pair] g%u fast %u m %u qlen %u passes %u out %u | stale %u inv %u slowsucc %u compact %u fixed(w1) %u | chase clk %u wall(100MHz) %u wrapscan clk %u\n",
-                    g, hp[g].fast, hp[g].m, hp[g].qlen, hp[g].passes, hp[g].n_out, hp[g].dbg[0], hp[g].dbg[1],
+            fprintf(stderr, "[mm-pair] g%u fast %u m %u qlen %u passes %u out %u rounds %u | stale %u inv %u slowsucc %u compact %u fixed(w1) %u | chase clk %u wall(100MHz) %u wrapscan clk %u\n",
+                    g, hp[g].fast, hp[g].m, hp[g].qlen, hp[g].passes, hp[g].n_out, hp[g].rounds, hp[g].dbg[0], hp[g].dbg[1],
                     hp[g].dbg[2], hp[g].dbg[3], hp[g].dbg[4], hp[g].dbg[5], hp[g].dbg[6], hp[g].dbg[7]);
     }
 

@@ -23,3 +23,21 @@ class EmuEngine(EngineBase):
         if EmuEngine._lib is None:
             EmuEngine._lib = load()
         super().__init__(cfg)
+
+
+def load_small():
+    subprocess.check_call(["make", "-C", _DIR, "--no-print-directory"], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(_DIR, "libmm_engine_emu_small.so"))
+    return bind(lib, "mm_")
+
+
+class EmuEngineSmall(EngineBase):
+    """Same source built with PK_T=512 / PL_MAX=1536: a few thousand players walk the tiled
+    path (tile tables, routing, compaction) and then the LDS-resident kernel."""
+    _prefix = "mm_"
+    _lib = None
+
+    def __init__(self, cfg):
+        if EmuEngineSmall._lib is None:
+            EmuEngineSmall._lib = load_small()
+        super().__init__(cfg)
