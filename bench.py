@@ -13,9 +13,16 @@ path shards with no data-path collective; every rank owns one engine and its own
 pool (another seed) — weak scaling.  RCCL is used only for the barrier and the max/sum of
 the timing/throughput scalars.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_walk):
-achieved = algorithmic bytes / HIP-event kernel time, algorithmic bytes = pair evaluations
-x 8 B (rating + cons of the candidate); `cpu_baseline` = the oracle
+Prints ONE JSON line (rank 0).  `roofline` is for the walk (the search proper: for a 1v1
+mode the pair path's kernel sequence kp_nx_init, [kp_tile_prep, kp_route, kp_tile_apply] x
+rounds, kp_late, kp_finish — DESIGN.md §4; for team modes the single kernel k_walk):
+achieved = algorithmic bytes / HIP-event time of that sequence on the engine's stream,
+algorithmic bytes = pair evaluations of the reference algorithm (the oracle's count, which
+the engine reproduces bit-exactly) x 8 B (rating + cons of the candidate).
+The engine does NOT touch every such pair — it keeps next[] pointers instead of rescanning —
+so `traffic` (HBM bytes from rocprofv3 PMC passes, profiles/) is far below the algorithmic
+bytes; the walk is bound by the latency of ~300-600 dependent passes, not by HBM
+(DESIGN.md §5).  `cpu_baseline` = the oracle
 (oracle/mode_r.c, a C port of the reference's sequential search, in-memory — an upper
 bound on what the BEAM service could do) timed on this box's host cores.
 """
@@ -157,12 +164,16 @@ def main():
         matched = float(s.item())
 
     if rank == 0:
+        walk_name = ("pair walk: kp_nx_init + (kp_tile_prep, kp_route, kp_tile_apply) x rounds + kp_late + kp_finish"
+                     if args.mode == "1v1" else "k_walk")
         k_ms = float(np.mean(walk_ms))
         achieved = pairs * bytes_per_pair / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         try:
             with open(args.traffic_json) as f:
-                traffic = json.load(f).get("k_walk_hbm_bytes_per_launch")
+                tj = json.load(f)
+            if tj.get("workload_players") == n and tj.get("mode") == args.mode:
+                traffic = tj.get("walk_hbm_bytes_per_tick")
         except Exception:
             pass
         line = {
@@ -185,13 +196,16 @@ def main():
             "pair_evals_per_s": pairs / (k_ms * 1e-3) if k_ms > 0 else None,
             "pairs_per_step": pairs,
             "passes_max": last.stats["passes_max"],
-            "kernel_ms": {"k_walk": k_ms, "bucket(count+scan+scatter)": float(np.mean(bucket_ms)),
+            "kernel_ms": {"walk": k_ms, "bucket(count+scan+scatter)": float(np.mean(bucket_ms)),
                           "d2h+bookkeeping": float(np.mean(copy_ms))},
-            "roofline": {"bound": "hbm", "kernel": "k_walk", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": walk_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": pairs * bytes_per_pair,
-                         "note": "Mode R is a sequential first-fit chain per rating group: the walk is "
-                                 "bound by chain-step latency (7 workgroups), not by HBM; see DESIGN.md"},
+                         "launch": "one tick = one walk to quiescence (HIP events around the kernel sequence)",
+                         "note": "Mode R is a chain of dependent first-fit steps (%d passes of the cursor for "
+                                 "the longest rating group); the engine replaces the per-pair rescans by "
+                                 "next[] pointers repaired incrementally, so it is bound by pass latency "
+                                 "(kernel boundaries + LDS/VALU issue), not by HBM; see DESIGN.md" % last.stats["passes_max"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, rating, cons, args.mode)

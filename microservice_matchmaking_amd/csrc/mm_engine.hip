@@ -762,9 +762,10 @@ struct mm_engine {
     uint32_t* d_pk_bits[2];
     uint32_t* d_pk_scratch;
     uint16_t* d_pk_wpre;
+    uint16_t* d_pk_g16;
     uint32_t* d_pk_tilectl;
     PairChain* h_pchains;      // pinned
-    uint32_t pk_bits_stride, pk_max_tiles;
+    uint32_t pk_bits_stride, pk_max_tiles, pk_stride;
     uint32_t pair_batch;       // MM_PAIR_BATCH: tiled rounds launched per host look at the chains
     bool force_generic;        // MM_FORCE_GENERIC=1: always walk with k_walk (A/B testing)
     bool pair_debug;           // MM_PAIR_DEBUG=1: print the pair path's diagnostics per tick
@@ -927,6 +928,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     }
     (void)hipFree(e->d_pk_scratch);
     (void)hipFree(e->d_pk_wpre);
+    (void)hipFree(e->d_pk_g16);
     (void)hipFree(e->d_pk_tilectl);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_chains) (void)hipHostFree(e->h_chains);
@@ -977,7 +979,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         const char* pt = getenv("MM_PAIR_TUNE");
         e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
         const char* pb = getenv("MM_PAIR_BATCH");
-        e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 8u;
+        e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 16u;
         if (e->pair_batch < 1u) e->pair_batch = 1u;
     }
     const size_t cap = cfg->capacity;
@@ -1007,17 +1009,19 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
     CREATE_CHK(hipMalloc((void**)&e->d_out_score, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(float)));
     CREATE_CHK(hipMalloc((void**)&e->d_out_pass, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(uint32_t)));
     {
-        const size_t gc = (size_t)cfg->n_groups * cap;
+        e->pk_stride = (uint32_t)((cap + 63) & ~(size_t)63);
+        const size_t gc = (size_t)cfg->n_groups * e->pk_stride;
         e->pk_bits_stride = (uint32_t)(cap / 32 + 4);
         CREATE_CHK(hipMalloc((void**)&e->d_pchains, cfg->n_groups * sizeof(PairChain)));
         e->pk_max_tiles = (uint32_t)(cap / PK_T + 2);
         for (int b = 0; b < 2; ++b) {
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_key[b], gc * sizeof(uint32_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_key[b], (gc + 64) * sizeof(uint32_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_oidx[b], gc * sizeof(uint32_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_nx16[b], gc * sizeof(uint16_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_nx16[b], (gc + 64) * sizeof(uint16_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_bits[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
         }
         CREATE_CHK(hipMalloc((void**)&e->d_pk_scratch, gc * sizeof(uint32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_pk_g16, (gc + 64) * sizeof(uint16_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
         CREATE_CHK(hipHostMalloc((void**)&e->h_pchains, cfg->n_groups * sizeof(PairChain), hipHostMallocDefault));
@@ -1218,6 +1222,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
     P.out_slot_stride = e->out_slot_stride;
     P.out_rec_stride = e->out_rec_stride;
     P.bits_stride = e->pk_bits_stride;
+    P.pstride = e->pk_stride;
     P.tune = e->pair_tune;
     P.chains = e->d_chains;
     P.pchains = e->d_pchains;
@@ -1230,6 +1235,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
     }
     P.scratch = e->d_pk_scratch;
     P.wpre = e->d_pk_wpre;
+    P.g16 = e->d_pk_g16;
     P.tilectl = e->d_pk_tilectl;
     P.max_tiles = e->pk_max_tiles;
     P.out_slots = e->d_out_slots;
@@ -1242,7 +1248,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
     hipLaunchKernelGGL(kp_nx_init, dim3((bound + NXI_SEG - 1u) / NXI_SEG + 1u, G), dim3(NXI_THREADS), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
     // ---- tiled rounds for the chains that do not fit one workgroup's LDS ----
-    if (bound > PL_MAX) {
+    if (bound >= PL_MAX) {
         uint32_t tiles = (bound + PK_T - 1u) / PK_T + 1u;
         if (tiles > e->pk_max_tiles) tiles = e->pk_max_tiles;
         for (;;) {
@@ -1342,6 +1348,14 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
             fprintf(stderr, "[mm-pair] g%u fast %u m %u qlen %u passes %u out %u rounds %u | stale %u inv %u slowsucc %u compact %u fixed(w1) %u | chase clk %u wall(100MHz) %u wrapscan clk %u\n",
                     g, hp[g].fast, hp[g].m, hp[g].qlen, hp[g].passes, hp[g].n_out, hp[g].rounds, hp[g].dbg[0], hp[g].dbg[1],
                     hp[g].dbg[2], hp[g].dbg[3], hp[g].dbg[4], hp[g].dbg[5], hp[g].dbg[6], hp[g].dbg[7]);
+        for (uint32_t g = 0; g < G; ++g)
+            if (hp[g].rounds)
+                fprintf(stderr, "[mm-pair] g%u tile1 cycles/round: prep load %u fix %u (items %.1f, pass1 %u) build %u doubling %u (rounds %.1f) publish %u | route head %u hops %u | apply load %u chase %u (steps %.1f) emit %u\n",
+                        g, hp[g].tm[0] / hp[g].rounds, hp[g].tm[1] / hp[g].rounds, (double)hp[g].tm[12] / hp[g].rounds,
+                        hp[g].tm[13] / hp[g].rounds, hp[g].tm[2] / hp[g].rounds,
+                        hp[g].tm[3] / hp[g].rounds, (double)hp[g].tm[5] / hp[g].rounds, hp[g].tm[4] / hp[g].rounds,
+                        hp[g].tm[6] / hp[g].rounds, hp[g].tm[7] / hp[g].rounds, hp[g].tm[8] / hp[g].rounds,
+                        hp[g].tm[9] / hp[g].rounds, (double)hp[g].tm[11] / hp[g].rounds, hp[g].tm[10] / hp[g].rounds);
     }
 
     uint32_t total = 0, after = 0, before = 0, pmax = 0, errf = 0;

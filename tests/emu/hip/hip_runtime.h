@@ -40,6 +40,7 @@ struct emu_dim3 {
     emu_dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 typedef emu_dim3 dim3;
+struct uint4 { unsigned x, y, z, w; };
 
 extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 

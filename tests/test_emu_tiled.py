@@ -1,0 +1,69 @@
+"""The pair (1v1) path's tiled kernels under the CPU shim, built with a tiny geometry
+(tests/emu/libmm_engine_emu_small.so: PK_T=512, PL_MAX=1536) so that pools of a few thousand
+players walk kp_tile_prep / kp_route / kp_tile_apply, compact, hand over to kp_late and come
+back bit-exact against the oracle.  Logic tests only; the parity gate is test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from emu_engine import EmuEngineSmall
+from helpers import assert_same_state, assert_same_tick, random_scenario
+from microservice_matchmaking_amd._abi import cons_make
+from microservice_matchmaking_amd.config import make_config, mode_1v1, mode_team
+
+
+def two_ticks(oracle_cls, n, seed, window, regions, lo=0, hi=5000):
+    cfg = make_config([mode_1v1(window=window, region_filter=regions > 1)], capacity=32768)
+    rng = np.random.default_rng(seed)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        for k in range(2):
+            nn = n if k == 0 else n // 2
+            rating = rng.integers(lo, hi + 1, size=nn).astype(np.int32)
+            cons = cons_make(0, rng.integers(0, regions, size=nn), 0, 0)
+            assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "tick %d" % k)
+            assert_same_state(a, b, cfg, "tick %d" % k)
+        return len(ma)
+
+
+def test_tiled_sparse_pool_far_and_none(oracle_cls):
+    """+-2 window: almost nobody fits; exit anchors without a partner inside the horizon."""
+    two_ticks(oracle_cls, 6000, seed=1, window=2, regions=4)
+
+
+def test_tiled_dense_pool(oracle_cls):
+    """+-500 window: nearly every player's partner is its neighbour (long in-tile chains)."""
+    assert two_ticks(oracle_cls, 8000, seed=2, window=500, regions=4) > 500
+
+
+def test_tiled_typical_pool_compacts_and_hands_over(oracle_cls):
+    assert two_ticks(oracle_cls, 7000, seed=7, window=60, regions=4) > 100
+
+
+def test_tiled_single_group_long_chain(oracle_cls):
+    """Everybody in one rating group: one chain of ten tiles."""
+    two_ticks(oracle_cls, 5000, seed=3, window=30, regions=2, lo=0, hi=1400)
+
+
+def test_tiled_with_cancels_and_mode_mix(oracle_cls):
+    """Cancel ticks take the generic kernel, the others the pair path; lobbies, queues and the
+    anchor (also one left in team 2 by a cancel) carry over between the two."""
+    cfg = make_config([mode_1v1(window=80, region_filter=True), mode_team(2, 2, 300, (1, 1))],
+                      capacity=16384)
+    rng = np.random.default_rng(11)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        random_scenario(rng, cfg, a, b, n_rounds=4, batch=3000, cancel_frac=0.03)
+
+
+def test_tiled_extreme_ratings_fall_back(oracle_cls):
+    """A chain whose rating span does not fit the packed key is walked by the generic kernel."""
+    cfg = make_config([mode_1v1(window=50)], capacity=8192)
+    rng = np.random.default_rng(5)
+    rating = rng.integers(3000, 3400, size=3000).astype(np.int32)
+    rating[::500] = np.asarray([2**31 - 1, -2**31, 2**31 - 5, -2**31 + 7, 2**30, -2**30], np.int32)
+    cons = cons_make(np.zeros(3000))
+    grp = np.full(3000, 4, np.uint8)          # host routed them all to one group
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        assert np.array_equal(a.enqueue(rating, cons, grp), b.enqueue(rating, cons, grp))
+        assert_same_tick(a.tick(0), b.tick(0), "extreme")
+        assert_same_state(a, b, cfg)

@@ -179,3 +179,41 @@ def test_gpu_edge_cases(gpu_cls, oracle_cls):
             e.enqueue(np.asarray([2**31 - 1, -2**31, 2**31 - 1, -2**31 + 10], np.int32), cons_make(np.zeros(4)))
         assert_same_tick(a.tick(0), b.tick(0), "extreme ratings")
         assert_same_state(a, b, cfg)
+
+
+@pytest.mark.parametrize("window,regions,party", [(0, 1, False), (5, 8, False), (400, 64, False),
+                                                  (100000, 1, False), (30, 4, True)])
+def test_gpu_pair_path_variants(gpu_cls, oracle_cls, window, regions, party):
+    """The 1v1 pair path (tiled rounds + LDS-resident walk) across predicate shapes: exact-rating
+    windows, a window wider than the rating span, many / no regions, the party filter."""
+    cfg = make_config([mode_1v1(window=window, region_filter=regions > 1, party_filter=party)], capacity=1 << 19)
+    rating, cons = make_pool(300000, seed=21, n_regions=regions, party_max=3 if party else 1)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+        ma, mb = a.tick(0), b.tick(0)
+        assert_same_tick(ma, mb, "w=%d r=%d" % (window, regions), SCORE_TOL)
+        assert_same_state(a, b, cfg)
+        check_properties(cfg, 0, rating, cons, ma, 300000)
+
+
+def test_gpu_pair_path_multi_tick_with_cancels(gpu_cls, oracle_cls):
+    """Survivors, the carried anchor and new arrivals over several ticks; a cancel tick in the
+    middle is walked by the generic kernel and hands its state back to the pair path."""
+    cfg = make_config([mode_1v1(window=25, region_filter=True)], capacity=1 << 20)
+    rng = np.random.default_rng(3)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        live = np.zeros(0, np.uint32)
+        for k, n in enumerate([400000, 150000, 5000, 250000]):
+            rating, cons = make_pool(n, seed=40 + k, dist="normal" if k % 2 else "uniform")
+            sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+            assert np.array_equal(sa, sb)
+            live = np.concatenate([live, sa])
+            if k == 2:
+                cs = rng.choice(live, size=3000, replace=False)
+                a.cancel(cs)
+                b.cancel(cs)
+                live = np.setdiff1d(live, cs)
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "tick %d" % k, SCORE_TOL)
+            assert_same_state(a, b, cfg, "tick %d" % k)
+            live = np.setdiff1d(live, ma.slots.ravel())
