@@ -1251,7 +1251,10 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
     if (bound >= PL_MAX) {
         uint32_t tiles = (bound + PK_T - 1u) / PK_T + 1u;
         if (tiles > e->pk_max_tiles) tiles = e->pk_max_tiles;
-        for (;;) {
+        for (uint32_t guard = 0;; ++guard) {
+            // every batch retires at least one pass of every tiled chain, a pass without a change
+            // ends the chain: capacity passes are an upper bound (never reached in practice)
+            if (guard > cfg.capacity / e->pair_batch + 64u) return MM_ERR_INTERNAL;
             HIPCHK(e, hipMemcpyAsync(e->h_pchains, e->d_pchains, G * sizeof(PairChain), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(e, hipStreamSynchronize(e->stream));
             bool tiled = false, compact = false;
