@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "normal"])
     ap.add_argument("--mode", default="1v1", choices=["1v1", "5v5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency leg")
+    ap.add_argument("--stream-qps", type=int, default=100_000)
+    ap.add_argument("--stream-seconds", type=float, default=3.0)
+    ap.add_argument("--stream-tick-ms", type=float, default=10.0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="optional {'k_walk_hbm_bytes_per_launch': ...} from a rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -88,6 +92,56 @@ def cpu_baseline(cfg, rating, cons, mode_name, budget_s=20.0):
                      "note": "one thread per rating group = the reference's own parallelism"},
         "host_cores": os.cpu_count(),
     }
+
+
+def stream_latency(make_engine, qps, seconds, tick_ms, window, seed=77):
+    """Second half of BASELINE.json's metric: match latency at a fixed enqueue rate.  Players
+    arrive as a Poisson stream (`qps`), every `tick_ms` of REAL time the arrivals of the period
+    are enqueued (host pointers, so the H2D copy and the bucketing kernels are inside) and one
+    tick is run; a matched player's latency = wall time at which its lobby came back from
+    mm_tick minus its arrival time.  Reported: p50 / p99 / max, matched players/s, backlog."""
+    import time as _t
+    from microservice_matchmaking_amd.synth import make_pool
+    eng = make_engine()
+    rng = np.random.default_rng(seed)
+    n_ticks = int(seconds * 1000.0 / tick_ms)
+    arrival = np.zeros(eng.cfg.capacity, dtype=np.float64)     # by slot
+    lat, tick_cost = [], []
+    matched = 0
+    # warm the kernels up outside the clock
+    r0, c0 = make_pool(2000, seed=seed)
+    eng.enqueue(r0, c0)
+    eng.tick(0)
+    eng.reset()
+    t_start = _t.perf_counter()
+    for k in range(n_ticks):
+        t_open, t_close = k * tick_ms * 1e-3, (k + 1) * tick_ms * 1e-3
+        n = int(rng.poisson(qps * tick_ms * 1e-3))
+        rating, cons = make_pool(n, seed=seed + 1 + k)
+        ts = np.sort(rng.uniform(t_open, t_close, size=n))
+        while _t.perf_counter() - t_start < t_close:            # the period has to be over
+            pass
+        t0 = _t.perf_counter()
+        slots = eng.enqueue(rating, cons)
+        arrival[slots] = ts
+        m = eng.tick(0)
+        t1 = _t.perf_counter()
+        tick_cost.append(t1 - t0)
+        if len(m):
+            s_ = m.slots.ravel()
+            lat.append((t1 - t_start) - arrival[s_])
+            matched += s_.size
+    elapsed = _t.perf_counter() - t_start
+    depth = int(eng.queue_depth(0).sum())
+    eng.close()
+    lat = np.concatenate(lat) if lat else np.zeros(1)
+    return {"enqueue_qps": qps, "tick_ms": tick_ms, "seconds": seconds, "mode": "1v1 +-%d, region filter" % window,
+            "p50_ms": float(np.percentile(lat, 50) * 1e3), "p99_ms": float(np.percentile(lat, 99) * 1e3),
+            "max_ms": float(lat.max() * 1e3), "matched_players_per_s": matched / elapsed,
+            "tick_cost_ms_mean": float(np.mean(tick_cost) * 1e3), "tick_cost_ms_p99": float(np.percentile(tick_cost, 99) * 1e3),
+            "backlog_players": depth, "kept_up": bool(elapsed < seconds * 1.05),
+            "note": "latency floor = half a tick period + the tick; a chain whose anchor nobody fits waits for "
+                    "arrivals (reference behaviour, docs/MATCH_CHECK.md section 4)"}
 
 
 def main():
@@ -209,6 +263,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, rating, cons, args.mode)
+        if world == 1 and not args.no_stream and args.mode == "1v1":
+            scfg = make_config(modes, capacity=1 << 20, device=local_rank, timing=False)
+            line["latency"] = stream_latency(lambda: Engine(scfg), args.stream_qps, args.stream_seconds,
+                                             args.stream_tick_ms, args.window)
         print(json.dumps(line), flush=True)
     eng.close()
     if dist_on:
