@@ -763,6 +763,12 @@ struct mm_engine {
     uint32_t* d_pk_scratch;
     uint16_t* d_pk_wpre;
     uint16_t* d_pk_g16;
+    uint32_t* d_pk_rec1;       // second REC buffer of the fused tiled path (the first is d_pk_scratch)
+    uint16_t* d_pk_exa[2];
+    uint32_t* d_pk_bitsp[2];
+    uint32_t* d_pk_headp[2];
+    bool pair_fused;           // MM_PAIR_FUSED=0: three launches per round instead of one (A/B testing)
+    uint32_t round_ctr;
     uint32_t* d_pk_tilectl;
     PairChain* h_pchains;      // pinned
     uint32_t pk_bits_stride, pk_max_tiles, pk_stride;
@@ -929,6 +935,8 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_pk_scratch);
     (void)hipFree(e->d_pk_wpre);
     (void)hipFree(e->d_pk_g16);
+    (void)hipFree(e->d_pk_rec1);
+    for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); }
     (void)hipFree(e->d_pk_tilectl);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_chains) (void)hipHostFree(e->h_chains);
@@ -978,6 +986,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         e->pair_debug = pd && pd[0] == '1';
         const char* pt = getenv("MM_PAIR_TUNE");
         e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
+        const char* pf = getenv("MM_PAIR_FUSED");
+        e->pair_fused = !(pf && pf[0] == '0');
+        e->round_ctr = 0;
         const char* pb = getenv("MM_PAIR_BATCH");
         e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 16u;
         if (e->pair_batch < 1u) e->pair_batch = 1u;
@@ -1022,6 +1033,12 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         }
         CREATE_CHK(hipMalloc((void**)&e->d_pk_scratch, gc * sizeof(uint32_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_pk_g16, (gc + 64) * sizeof(uint16_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_pk_rec1, gc * sizeof(uint32_t)));
+        for (int b = 0; b < 2; ++b) {
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_exa[b], (gc + 64) * sizeof(uint16_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_bitsp[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_headp[b], (size_t)cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
+        }
         CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
         CREATE_CHK(hipHostMalloc((void**)&e->h_pchains, cfg->n_groups * sizeof(PairChain), hipHostMallocDefault));
@@ -1236,6 +1253,9 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
     P.scratch = e->d_pk_scratch;
     P.wpre = e->d_pk_wpre;
     P.g16 = e->d_pk_g16;
+    P.rec2[0] = e->d_pk_scratch;
+    P.rec2[1] = e->d_pk_rec1;
+    for (int b = 0; b < 2; ++b) { P.exa[b] = e->d_pk_exa[b]; P.bitsp[b] = e->d_pk_bitsp[b]; P.headp[b] = e->d_pk_headp[b]; }
     P.tilectl = e->d_pk_tilectl;
     P.max_tiles = e->pk_max_tiles;
     P.out_slots = e->d_out_slots;
@@ -1276,10 +1296,23 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
                 HIPCHK(e, hipGetLastError());
                 continue;                       // look at the new lengths before the next batch
             }
-            for (uint32_t r = 0; r < e->pair_batch; ++r) {
-                hipLaunchKernelGGL(kp_tile_prep, dim3(tiles, G), dim3(PT_THREADS), 0, e->stream, P);
-                hipLaunchKernelGGL(kp_route, dim3(G), dim3(PR_THREADS), 0, e->stream, P);
-                hipLaunchKernelGGL(kp_tile_apply, dim3(tiles, G), dim3(PA_THREADS), 0, e->stream, P);
+            if (e->pair_fused) {
+                // one launch per pass; the first of a batch only prepares, the commit brings the
+                // latest parity back into the chains' committed state
+                uint32_t r = e->round_ctr;
+                hipLaunchKernelGGL(kp_round, dim3(tiles, G), dim3(PT_THREADS), 0, e->stream, P, r, 1u);
+                ++r;
+                for (uint32_t b = 0; b < e->pair_batch; ++b, ++r)
+                    hipLaunchKernelGGL(kp_round, dim3(tiles, G), dim3(PT_THREADS), 0, e->stream, P, r, 0u);
+                hipLaunchKernelGGL(kp_round_commit, dim3(tiles, G), dim3(256), 0, e->stream, P, r);
+                hipLaunchKernelGGL(kp_round_stage, dim3(G), dim3(64), 0, e->stream, P, r);
+                e->round_ctr = r;
+            } else {
+                for (uint32_t r = 0; r < e->pair_batch; ++r) {
+                    hipLaunchKernelGGL(kp_tile_prep, dim3(tiles, G), dim3(PT_THREADS), 0, e->stream, P);
+                    hipLaunchKernelGGL(kp_route, dim3(G), dim3(PR_THREADS), 0, e->stream, P);
+                    hipLaunchKernelGGL(kp_tile_apply, dim3(tiles, G), dim3(PA_THREADS), 0, e->stream, P);
+                }
             }
             HIPCHK(e, hipGetLastError());
         }
