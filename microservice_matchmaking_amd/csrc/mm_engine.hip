@@ -990,7 +990,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         e->pair_fused = !(pf && pf[0] == '0');
         e->round_ctr = 0;
         const char* pb = getenv("MM_PAIR_BATCH");
-        e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 16u;
+        e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 32u;
         if (e->pair_batch < 1u) e->pair_batch = 1u;
     }
     const size_t cap = cfg->capacity;
