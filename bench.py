@@ -14,8 +14,8 @@ pool (another seed) — weak scaling.  RCCL is used only for the barrier and the
 the timing/throughput scalars.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the walk (the search proper: for a 1v1
-mode the pair path's kernel sequence kp_nx_init, [kp_tile_prep, kp_route, kp_tile_apply] x
-rounds, kp_late, kp_finish — DESIGN.md §4; for team modes the single kernel k_walk):
+mode the pair path's kernel sequence kp_nx_init, kp_round x rounds (one launch per pass of the
+cursor), kp_late, kp_finish — DESIGN.md §4; for team modes the single kernel k_walk):
 achieved = algorithmic bytes / HIP-event time of that sequence on the engine's stream,
 algorithmic bytes = pair evaluations of the reference algorithm (the oracle's count, which
 the engine reproduces bit-exactly) x 8 B (rating + cons of the candidate).
@@ -218,7 +218,7 @@ def main():
         matched = float(s.item())
 
     if rank == 0:
-        walk_name = ("pair walk: kp_nx_init + (kp_tile_prep, kp_route, kp_tile_apply) x rounds + kp_late + kp_finish"
+        walk_name = ("pair walk: kp_nx_init + kp_round x rounds + kp_late + kp_finish"
                      if args.mode == "1v1" else "k_walk")
         k_ms = float(np.mean(walk_ms))
         achieved = pairs * bytes_per_pair / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0

@@ -783,8 +783,10 @@ struct mm_engine {
     std::vector<uint8_t> h_state;
     uint32_t next_slot;
     uint32_t cancel_pending;
-    std::vector<uint32_t> r_slots, r_group, r_pass, r_released;
-    std::vector<float> r_score;
+    std::vector<uint32_t> r_group, r_released;
+    uint32_t* h_rslots;        // pinned: the last tick's lobbies (slots, score, pass), emission order
+    float* h_rscore;
+    uint32_t* h_rpass;
     uint32_t r_n, r_L;
 };
 
@@ -939,6 +941,9 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); }
     (void)hipFree(e->d_pk_tilectl);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
+    if (e->h_rslots) (void)hipHostFree(e->h_rslots);
+    if (e->h_rscore) (void)hipHostFree(e->h_rscore);
+    if (e->h_rpass) (void)hipHostFree(e->h_rpass);
     if (e->h_chains) (void)hipHostFree(e->h_chains);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (int i = 0; i < 4; ++i)
@@ -1042,6 +1047,10 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
         CREATE_CHK(hipHostMalloc((void**)&e->h_pchains, cfg->n_groups * sizeof(PairChain), hipHostMallocDefault));
+        // a tick emits at most (cap + lobby) / 2 lobbies per group, cap + lobbies-in-progress players overall
+        CREATE_CHK(hipHostMalloc((void**)&e->h_rslots, (cap + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
+        CREATE_CHK(hipHostMalloc((void**)&e->h_rscore, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(float), hipHostMallocDefault));
+        CREATE_CHK(hipHostMalloc((void**)&e->h_rpass, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
         CREATE_CHK(hipMemsetAsync(e->d_pchains, 0, cfg->n_groups * sizeof(PairChain), e->stream));
     }
     CREATE_CHK(hipHostMalloc((void**)&e->h_chains, e->n_chains * sizeof(ChainDev), hipHostMallocDefault));
@@ -1407,19 +1416,17 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
         if (c.passes > pmax) pmax = c.passes;
     }
     if (errf) return MM_ERR_INTERNAL;
-    e->r_slots.resize((size_t)total * M.L);
-    e->r_score.resize(total);
-    e->r_pass.resize(total);
+    if ((size_t)total * M.L > (size_t)cfg.capacity + (size_t)MM_MAX_LOBBY * G) return MM_ERR_INTERNAL;
     e->r_group.resize(total);
     uint32_t k = 0;
     for (uint32_t g = 0; g < G; ++g) {   // group-major emission order
         const uint32_t ng = e->h_chains[mode * G + g].n_out;
         if (!ng) continue;
-        HIPCHK(e, hipMemcpyAsync(&e->r_slots[(size_t)k * M.L], e->d_out_slots + (size_t)g * e->out_slot_stride,
+        HIPCHK(e, hipMemcpyAsync(&e->h_rslots[(size_t)k * M.L], e->d_out_slots + (size_t)g * e->out_slot_stride,
                                  (size_t)ng * M.L * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipMemcpyAsync(&e->r_score[k], e->d_out_score + (size_t)g * e->out_rec_stride, ng * sizeof(float),
+        HIPCHK(e, hipMemcpyAsync(&e->h_rscore[k], e->d_out_score + (size_t)g * e->out_rec_stride, ng * sizeof(float),
                                  hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipMemcpyAsync(&e->r_pass[k], e->d_out_pass + (size_t)g * e->out_rec_stride, ng * sizeof(uint32_t),
+        HIPCHK(e, hipMemcpyAsync(&e->h_rpass[k], e->d_out_pass + (size_t)g * e->out_rec_stride, ng * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, e->stream));
         for (uint32_t i = 0; i < ng; ++i) e->r_group[k + i] = g;
         k += ng;
@@ -1431,7 +1438,7 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
     HIPCHK(e, hipStreamSynchronize(e->stream));
     // ActiveUser.remove_user for matched players (game-lobby/worker.ex:73-103) and the
     // slots the liveness filter released
-    for (size_t i = 0; i < e->r_slots.size(); ++i) e->h_state[e->r_slots[i]] = MM_ST_FREE;
+    for (size_t i = 0, ns = (size_t)total * M.L; i < ns; ++i) e->h_state[e->h_rslots[i]] = MM_ST_FREE;
     for (uint32_t i = 0; i < nrel; ++i) e->h_state[e->r_released[i]] = MM_ST_FREE;
     e->cancel_pending = e->cancel_pending >= nrel ? e->cancel_pending - nrel : 0;
     {
@@ -1467,10 +1474,10 @@ extern "C" int mm_matches(mm_engine* e, uint32_t first, uint32_t count, uint32_t
     if (!e) return MM_ERR_INVALID_ARG;
     if (first > e->r_n || count > e->r_n - first) return MM_ERR_RANGE;
     if (count == 0) return MM_OK;
-    if (slots) memcpy(slots, &e->r_slots[(size_t)first * e->r_L], (size_t)count * e->r_L * sizeof(uint32_t));
-    if (score) memcpy(score, &e->r_score[first], count * sizeof(float));
+    if (slots) memcpy(slots, &e->h_rslots[(size_t)first * e->r_L], (size_t)count * e->r_L * sizeof(uint32_t));
+    if (score) memcpy(score, &e->h_rscore[first], count * sizeof(float));
     if (group) memcpy(group, &e->r_group[first], count * sizeof(uint32_t));
-    if (pass) memcpy(pass, &e->r_pass[first], count * sizeof(uint32_t));
+    if (pass) memcpy(pass, &e->h_rpass[first], count * sizeof(uint32_t));
     return MM_OK;
 }
 
