@@ -217,3 +217,20 @@ def test_gpu_pair_path_multi_tick_with_cancels(gpu_cls, oracle_cls):
             assert_same_tick(ma, mb, "tick %d" % k, SCORE_TOL)
             assert_same_state(a, b, cfg, "tick %d" % k)
             live = np.setdiff1d(live, ma.slots.ravel())
+
+
+def test_gpu_1v1_10m_pool(gpu_cls, oracle_cls):
+    """BASELINE cfg-4 on one device: 10M players, 1v1 +-25 + region filter (chains of 1-3M players,
+    hundreds of tiles per chain).  On a node the same chains spread over the ranks by rating group
+    (sharding.GroupSharding), each rank running exactly this code on its groups."""
+    n = 10_000_000
+    cfg = make_config([mode_1v1(window=25, region_filter=True)], capacity=1 << 24)
+    rating, cons = make_pool(n, seed=4)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        sa = a.enqueue(rating, cons)
+        assert sa[0] == 0 and sa[-1] == n - 1
+        b.enqueue(rating, cons)
+        ma, mb = a.tick(0), b.tick(0)
+        assert_same_tick(ma, mb, "10M", SCORE_TOL)
+        assert_same_state(a, b, cfg)
+        check_properties(cfg, 0, rating, cons, ma, n)
