@@ -24,7 +24,11 @@
 //           (ballot + ffs arg-min over queue position), in-place survivor compaction.
 //           The chain is inherently sequential (each match decides the next anchor), so
 //           the parallelism is: 64 candidates per anchor step, tile load/compaction on the
-//           other waves, and independent chains on independent CUs.
+//           other waves, and independent chains on independent CUs.  Walks every mode; the
+//           fallback of the pair path.
+//   mm_pair.inc   the 1v1 walk: next[] pointers for every queued player, one launch per pass
+//           over all tiles of all chains (kp_round), an LDS-resident speculative pointer chase
+//           for short chains (kp_late).  DESIGN.md §4.3.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
@@ -481,6 +485,74 @@ static __device__ bool lobby_has_cancelled(const LobbyDev& lb, const ModeDev& M,
     return any;
 }
 
+// The open lobby as wave 0 sees it while it walks: a register copy (uniform across the lanes)
+// of everything match_check needs — anchor, seats per team, players per (team, role), team
+// rating sums, free seats per role — so that a seat costs a handful of ALU operations and one
+// record written to the LDS lobby by lane 0, not a re-count of the lobby.
+struct LobbySum {
+    uint32_t n, cnt[MM_MAX_TEAMS], rc[MM_MAX_TEAMS];     // rc: 4 bits per role
+    long long sum[MM_MAX_TEAMS];
+    int32_t ar;
+    uint32_t ac, free, full;                              // free / full: 4 bits per role, seats over all teams
+};
+
+static __device__ void lsum_load(LobbySum& L, const LobbyDev& lb, const ModeDev& M)
+{
+    L.n = lb.n;
+    L.full = 0;
+    for (uint32_t rr = 0; rr < M.n_roles; ++rr) L.full |= (M.teams * M.quota[rr]) << (4u * rr);   // <= 16 only for
+    uint32_t used = 0;                                                                            // a one-role mode
+    int at = -1;
+#pragma unroll
+    for (uint32_t t = 0; t < MM_MAX_TEAMS; ++t) {
+        L.cnt[t] = t < M.teams ? lb.cnt[t] : 0u;
+        L.rc[t] = 0;
+        L.sum[t] = 0;
+        for (uint32_t k = 0; k < L.cnt[t]; ++k) {
+            L.rc[t] += 1u << (4u * ((lb.cons[t][k] >> 16) & 7u));
+            L.sum[t] += lb.rating[t][k];
+        }
+        used += L.rc[t];
+        if (at < 0 && L.cnt[t]) at = (int)t;
+    }
+    L.free = L.full - used;                               // per nibble: no borrow, used <= full
+    L.ar = at >= 0 ? lb.rating[at][0] : 0;
+    L.ac = at >= 0 ? lb.cons[at][0] : 0u;
+    __builtin_amdgcn_wave_barrier();                      // every lane has read the lobby before lane 0 writes it again
+}
+
+// docs/MATCH_CHECK.md §2.3-2.4 for a player already known to pass §2.2 (or an empty lobby):
+// the eligible team with the smallest rating sum, lowest index on a tie; -1 if no team has a
+// free seat of the role.
+static __device__ int lsum_seat(LobbySum& L, LobbyDev& lb, const ModeDev& M, int32_t r, uint32_t cn, uint32_t slot, int lane)
+{
+    const uint32_t role = (cn >> 16) & 7u;
+    int best = -1;
+    long long best_sum = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < MM_MAX_TEAMS; ++t) {
+        if (t >= M.teams) continue;
+        if (((L.rc[t] >> (4u * role)) & 15u) >= M.quota[role]) continue;
+        if (best < 0 || L.sum[t] < best_sum) { best = (int)t; best_sum = L.sum[t]; }
+    }
+    if (best < 0) return -1;
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < MM_MAX_TEAMS; ++t)
+        if ((int)t == best) { k = L.cnt[t]; L.cnt[t] = k + 1u; L.rc[t] += 1u << (4u * role); L.sum[t] += r; }
+    if (L.n == 0u) { L.ar = r; L.ac = cn; }               // first seat of an empty lobby: the anchor (team 1)
+    L.n += 1u;
+    L.free -= 1u << (4u * role);
+    if (lane == 0) {
+        lb.slot[best][k] = slot;
+        lb.rating[best][k] = r;
+        lb.cons[best][k] = cn;
+        lb.cnt[best] = k + 1u;
+        lb.n = L.n;
+    }
+    return best;
+}
+
 __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
 {
     __shared__ int32_t t_rating[WK_TILE];
@@ -490,6 +562,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
     __shared__ uint32_t t_pref[WK_TILE / 32];       // exclusive survivor prefix per mask word
     __shared__ LobbyDev lb;
     __shared__ uint32_t s_changed, s_total, s_w0tot;
+    __shared__ uint32_t s_cmd[6];                   // wave 0 -> block: {kind, from, anchor rating, anchor cons, free seats, found}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = blockIdx.x;
@@ -515,6 +588,8 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
     __syncthreads();
 
     // wave-0 chain state (uniform across the wave)
+    LobbySum L;                                 // register copy of the LDS lobby (see lsum_load)
+    bool sum_valid = false;
     bool first_stale = false;
     uint32_t n_out = 0, err = 0;
     unsigned long long pairs = 0, scanned = 0;
@@ -543,12 +618,16 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
             if (tid < WK_TILE / 32) t_mask[tid] = 0;
             __syncthreads();
 
-            // ---- wave 0: the first-fit chain over the tile ----
+            // ---- wave 0: the first-fit chain over the tile.  When 64 candidates in a row were
+            //      all rejected it asks the whole block for the next candidate the lobby would take
+            //      (a starving lobby rejects thousands in a row: one block-wide step per tile then). ----
+            uint32_t p = 0;
+            for (;;) {
             if (wave == 0) {
-                uint32_t p = 0;
                 if (first_stale) {
                     // first attempt after a cancel: judged against the stale lobby, then filter
                     first_stale = false;
+                    sum_valid = false;
                     if (lb.n) pairs += 1;
                     const int t = lobby_try_seat(lb, M, t_rating[0], t_cons[0], t_slot[0], lane);
                     lobby_filter(lb, M, P.state, P.released, P.n_released, lane);
@@ -559,22 +638,20 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
                     p = 1;
                 }
                 while (p < cnt) {
-                    if (lb.n == 0) {
+                    if (!sum_valid) { wave_sync(); lsum_load(L, lb, M); sum_valid = true; }
+                    if (L.n == 0) {
                         // empty lobby: the popped player opens it (MATCH_CHECK.md §2.1)
-                        const int t = lobby_try_seat(lb, M, t_rating[p], t_cons[p], t_slot[p], lane);
+                        const int t = lsum_seat(L, lb, M, t_rating[p], t_cons[p], t_slot[p], lane);
                         if (t < 0) err |= MM_ERRF_SEAT_INVARIANT;
                         if (lane == 0) atomicOr(&t_mask[p >> 5], 1u << (p & 31));
                         changed = true;
                         ++p;
                         continue;
                     }
-                    // anchor + free seats per role
-                    int at = 0;
-                    for (uint32_t t = 0; t < M.teams; ++t)
-                        if (lb.cnt[t]) { at = (int)t; break; }
-                    const int32_t ar = lb.rating[at][0];
-                    const uint32_t ac = lb.cons[at][0];
-                    uint32_t total_free = M.L - lb.n;
+                    const int32_t ar = L.ar;
+                    const uint32_t ac = L.ac;
+                    const uint32_t s_free = L.free;
+                    uint32_t total_free = M.L - L.n;
                     // 64 candidates, one per lane
                     const uint32_t i = p + lane;
                     const bool valid = i < cnt;
@@ -583,25 +660,25 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
                     uint32_t cn = 0;
                     if (valid) { r = t_rating[i]; cn = t_cons[i]; }
                     const uint32_t d = r >= ar ? (uint32_t)r - (uint32_t)ar : (uint32_t)ar - (uint32_t)r;
-                    const bool ok = valid && d <= M.window && (((cn ^ ac) & M.eqmask) == 0);
                     const uint32_t role = (cn >> 16) & 0xFu;
+                    const bool ok = valid && d <= M.window && (((cn ^ ac) & M.eqmask) == 0) &&
+                                    ((s_free >> (4u * (role & 7u))) & 15u) != 0u;
                     unsigned long long S = 0;
-                    for (uint32_t rr = 0; rr < M.n_roles; ++rr) {
-                        uint32_t have = 0;
-                        for (uint32_t t = 0; t < M.teams; ++t)
-                            for (uint32_t k = 0; k < lb.cnt[t]; ++k)
-                                have += ((lb.cons[t][k] >> 16) & 0xFu) == rr ? 1u : 0u;
-                        uint32_t fr = M.teams * M.quota[rr] - have;
-                        unsigned long long mk = __ballot(ok && role == rr);
-                        while (fr && mk) {                 // first `fr` candidates of the role
-                            S |= mk & (~mk + 1ull);
-                            mk &= mk - 1ull;
-                            --fr;
+                    if (__ballot(ok)) {
+                        for (uint32_t rr = 0; rr < M.n_roles; ++rr) {
+                            uint32_t fr = (s_free >> (4u * rr)) & 15u;
+                            unsigned long long mk = __ballot(ok && role == rr);
+                            while (fr && mk) {                 // first `fr` candidates of the role
+                                S |= mk & (~mk + 1ull);
+                                mk &= mk - 1ull;
+                                --fr;
+                            }
                         }
                     }
                     if (S == 0) {
                         pairs += nvalid;
                         p += 64;
+                        if (p < cnt) break;                     // let the block look ahead
                         continue;
                     }
                     changed = true;
@@ -613,7 +690,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
                         const uint32_t b = (uint32_t)__ffsll(todo) - 1u;
                         todo &= todo - 1ull;
                         const uint32_t e = p + b;
-                        const int t = lobby_try_seat(lb, M, t_rating[e], t_cons[e], t_slot[e], lane);
+                        const int t = lsum_seat(L, lb, M, t_rating[e], t_cons[e], t_slot[e], lane);
                         if (t < 0) err |= MM_ERRF_SEAT_INVARIANT;
                     }
                     if ((S >> lane) & 1ull) atomicOr(&t_mask[(p + lane) >> 5], 1u << ((p + lane) & 31));
@@ -623,7 +700,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
                         continue;
                     }
                     // ---- is_filled: emit in team order (search/worker.ex:313-319) ----
-                    if (lb.n != M.L) err |= MM_ERRF_SEAT_INVARIANT;
+                    if (L.n != M.L) err |= MM_ERRF_SEAT_INVARIANT;
                     wave_sync();
                     if (lane == 0) {
                         if (n_out < P.out_cap) {
@@ -647,11 +724,46 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
                         for (uint32_t t = 0; t < M.teams; ++t) lb.cnt[t] = 0;
                     }
                     wave_sync();
+                    L.n = 0;                                    // the register copy: an empty lobby
+                    L.free = L.full;
+#pragma unroll
+                    for (uint32_t t = 0; t < MM_MAX_TEAMS; ++t) { L.cnt[t] = 0; L.rc[t] = 0; L.sum[t] = 0; }
                     if (n_out >= P.out_cap) err |= MM_ERRF_OUT_OVERFLOW;
                     ++n_out;
                     pairs += last + 1u;
                     p += last + 1u;
                 }
+                if (lane == 0) {
+                    s_cmd[0] = p < cnt ? 1u : 0u;               // 1 = look ahead from p, 0 = tile done
+                    s_cmd[1] = p;
+                    s_cmd[2] = (uint32_t)L.ar;
+                    s_cmd[3] = L.ac;
+                    s_cmd[4] = L.free;
+                    s_cmd[5] = 0xFFFFFFFFu;
+                }
+            }
+            __syncthreads();
+            if (s_cmd[0] == 0u) break;
+            {
+                // first candidate at or after s_cmd[1] that fits the anchor and whose role has a free seat
+                const int32_t c_ar = (int32_t)s_cmd[2];
+                const uint32_t c_ac = s_cmd[3], c_free = s_cmd[4];
+                for (uint32_t i = s_cmd[1] + (uint32_t)tid; i < cnt; i += WK_THREADS) {
+                    const int32_t r = t_rating[i];
+                    const uint32_t cn = t_cons[i];
+                    const uint32_t d = r >= c_ar ? (uint32_t)r - (uint32_t)c_ar : (uint32_t)c_ar - (uint32_t)r;
+                    if (d <= M.window && (((cn ^ c_ac) & M.eqmask) == 0) && ((c_free >> (4u * ((cn >> 16) & 7u))) & 15u)) {
+                        atomicMin(&s_cmd[5], i);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const uint32_t f = s_cmd[5] < cnt ? s_cmd[5] : cnt;
+                pairs += f - p;                                  // everybody in between was rejected
+                p = f;
+            }
             }
             __syncthreads();
 
@@ -672,6 +784,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
             __syncthreads();
             const uint32_t w0tot = s_w0tot;
             const uint32_t total = w0tot + s_total;
+            if (wr != rd || total != cnt)          // nobody left the queue so far in this pass: all in place
             for (uint32_t i = tid; i < cnt; i += WK_THREADS) {
                 const uint32_t w = i >> 5, b = i & 31u;
                 const uint32_t mw = t_mask[w];
