@@ -493,7 +493,8 @@ struct LobbySum {
     uint32_t n, cnt[MM_MAX_TEAMS], rc[MM_MAX_TEAMS];     // rc: 4 bits per role
     long long sum[MM_MAX_TEAMS];
     int32_t ar;
-    uint32_t ac, free, full;                              // free / full: 4 bits per role, seats over all teams
+    uint32_t ac, at;                                      // anchor: rating, cons, its team (MM_MAX_TEAMS: none)
+    uint32_t free, full;                                  // 4 bits per role, seats over all teams
 };
 
 static __device__ void lsum_load(LobbySum& L, const LobbyDev& lb, const ModeDev& M)
@@ -518,6 +519,7 @@ static __device__ void lsum_load(LobbySum& L, const LobbyDev& lb, const ModeDev&
     L.free = L.full - used;                               // per nibble: no borrow, used <= full
     L.ar = at >= 0 ? lb.rating[at][0] : 0;
     L.ac = at >= 0 ? lb.cons[at][0] : 0u;
+    L.at = at >= 0 ? (uint32_t)at : (uint32_t)MM_MAX_TEAMS;
     __builtin_amdgcn_wave_barrier();                      // every lane has read the lobby before lane 0 writes it again
 }
 
@@ -540,7 +542,10 @@ static __device__ int lsum_seat(LobbySum& L, LobbyDev& lb, const ModeDev& M, int
 #pragma unroll
     for (uint32_t t = 0; t < MM_MAX_TEAMS; ++t)
         if ((int)t == best) { k = L.cnt[t]; L.cnt[t] = k + 1u; L.rc[t] += 1u << (4u * role); L.sum[t] += r; }
-    if (L.n == 0u) { L.ar = r; L.ac = cn; }               // first seat of an empty lobby: the anchor (team 1)
+    // the anchor is the first player of the lowest-numbered non-empty team (MATCH_CHECK.md §2.1):
+    // a seat in a team below the anchor's (empty until now — a cancel emptied it, or the lobby
+    // was empty) makes this player the anchor
+    if ((uint32_t)best < L.at) { L.ar = r; L.ac = cn; L.at = (uint32_t)best; }
     L.n += 1u;
     L.free -= 1u << (4u * role);
     if (lane == 0) {
@@ -651,7 +656,6 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
                     const int32_t ar = L.ar;
                     const uint32_t ac = L.ac;
                     const uint32_t s_free = L.free;
-                    uint32_t total_free = M.L - L.n;
                     // 64 candidates, one per lane
                     const uint32_t i = p + lane;
                     const bool valid = i < cnt;
@@ -682,21 +686,28 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
                         continue;
                     }
                     changed = true;
-                    const uint32_t nS = (uint32_t)__popcll(S);
-                    const bool fills = nS >= total_free;
-                    const uint32_t last = 63u - (uint32_t)__clzll((long long)S);   // highest seated lane
-                    unsigned long long todo = S;
+                    // seat the selected candidates in queue order; stop at the one that fills the
+                    // lobby, or that becomes the new anchor (the rest of the chunk was judged
+                    // against the old one and is looked at again)
+                    unsigned long long todo = S, seated = 0;
+                    uint32_t stop = 64u;
+                    bool fills = false;
                     while (todo) {
                         const uint32_t b = (uint32_t)__ffsll(todo) - 1u;
                         todo &= todo - 1ull;
                         const uint32_t e = p + b;
+                        const uint32_t at0 = L.at;
                         const int t = lsum_seat(L, lb, M, t_rating[e], t_cons[e], t_slot[e], lane);
                         if (t < 0) err |= MM_ERRF_SEAT_INVARIANT;
+                        seated |= 1ull << b;
+                        if (L.n == M.L) { fills = true; stop = b; break; }
+                        if (L.at != at0) { stop = b; break; }
                     }
-                    if ((S >> lane) & 1ull) atomicOr(&t_mask[(p + lane) >> 5], 1u << ((p + lane) & 31));
+                    if ((seated >> lane) & 1ull) atomicOr(&t_mask[(p + lane) >> 5], 1u << ((p + lane) & 31));
+                    const uint32_t last = stop;
                     if (!fills) {
-                        pairs += nvalid;
-                        p += 64;
+                        if (stop < 64u) { pairs += stop + 1u; p += stop + 1u; }     // new anchor: judge the rest again
+                        else { pairs += nvalid; p += 64; }
                         continue;
                     }
                     // ---- is_filled: emit in team order (search/worker.ex:313-319) ----
@@ -725,6 +736,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
                     }
                     wave_sync();
                     L.n = 0;                                    // the register copy: an empty lobby
+                    L.at = MM_MAX_TEAMS;
                     L.free = L.full;
 #pragma unroll
                     for (uint32_t t = 0; t < MM_MAX_TEAMS; ++t) { L.cnt[t] = 0; L.rc[t] = 0; L.sum[t] = 0; }

@@ -81,3 +81,40 @@ def test_emu_ring_wrap_and_full(oracle_cls):
             with pytest.raises(MMError) as ei:
                 e.enqueue(np.full(1, 1000, np.int32), cons_make(np.zeros(1)))  # slot 2 still live
             assert ei.value.status == -4
+
+
+def test_emu_anchor_moves_to_a_lower_team_mid_lobby(oracle_cls):
+    """A cancel empties team 1 of an open lobby; the next player seated there becomes the anchor
+    (first player of the lowest-numbered non-empty team, MATCH_CHECK.md §2.1) in the middle of a
+    64-candidate step, so the candidates after it are judged against the NEW anchor.  Found by
+    tools/gpu_stress.py; pinned here against the oracle and the literal restatement."""
+    from test_oracle_literal import literal_stage, literal_tick, to_payload
+    cfg = make_config([mode_team(2, 2, 300, (1, 1))], capacity=256)
+    from microservice_matchmaking_amd._abi import cons_make
+    r1 = np.asarray([1000, 1200, 1250], np.int32)
+    c1 = cons_make(0, 0, 0, [0, 0, 1])
+    #        q0: no seat of role 0 in the stale lobby -> requeued;  q1 becomes the anchor (1450);
+    #        q2 would fit the old anchor (1200) but not the new one;  q3, q4 complete the lobby
+    r2 = np.asarray([950, 1450, 1000, 1300, 1500, 1210], np.int32)
+    c2 = cons_make(0, 0, 0, [0, 1, 1, 0, 1, 0])
+    stage = literal_stage(cfg)
+    with EmuEngine(cfg) as a, oracle_cls(cfg) as b:
+        for e in (a, b):
+            assert e.enqueue(r1, c1).tolist() == [0, 1, 2]
+        for s_, r_, c_ in zip([0, 1, 2], r1, c1):
+            stage.deliver(to_payload(s_, r_, c_))
+        assert_same_tick(a.tick(0), b.tick(0), "open the lobby")
+        assert literal_tick(stage, cfg)[0] == []
+        for e in (a, b):
+            e.cancel(np.asarray([0, 2], np.uint32))          # team 1 of the lobby is gone
+            assert e.enqueue(r2, c2).tolist() == [3, 4, 5, 6, 7, 8]
+        for s_ in (0, 2):
+            stage.cancel(s_)
+        for s_, r_, c_ in zip(range(3, 9), r2, c2):
+            stage.deliver(to_payload(s_, r_, c_))
+        ma, mb = a.tick(0), b.tick(0)
+        assert_same_tick(ma, mb, "anchor moved")
+        assert_same_state(a, b, cfg)
+        lit = literal_tick(stage, cfg)[0]
+        assert [x[2] for x in lit] == mb.slots.tolist()
+        assert 5 not in mb.slots.ravel().tolist()            # q2 (1000) never sat with anchor 1450
