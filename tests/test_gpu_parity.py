@@ -234,3 +234,16 @@ def test_gpu_1v1_10m_pool(gpu_cls, oracle_cls):
         assert_same_tick(ma, mb, "10M", SCORE_TOL)
         assert_same_state(a, b, cfg)
         check_properties(cfg, 0, rating, cons, ma, n)
+
+
+def test_gpu_randomised_stress_short(gpu_cls, monkeypatch):
+    """Ten seconds of tools/gpu_stress.py: seeded random pools / predicates / multi-tick scripts
+    with arrivals and cancels, every tick bit-exact against the oracle."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_stress.py")
+    spec = importlib.util.spec_from_file_location("gpu_stress", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr("sys.argv", ["gpu_stress.py", "10", "3"])
+    mod.main()
