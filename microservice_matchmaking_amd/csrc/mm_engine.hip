@@ -1359,7 +1359,7 @@ extern "C" int mm_cancel(mm_engine* e, uint32_t n, const uint32_t* slot)
 
 // The pair path (mm_pair.inc) for every chain of `mode` it is eligible for; the others are
 // left to k_walk (PairChain.fast == 0).  All launches are asynchronous on the engine stream.
-static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
+static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
 {
     const mm_config& cfg = e->cfg;
     const uint32_t G = cfg.n_groups;
@@ -1375,6 +1375,10 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M)
     P.bits_stride = e->pk_bits_stride;
     P.pstride = e->pk_stride;
     P.tune = e->pair_tune;
+    P.purge = purge ? 1u : 0u;
+    P.state = e->d_state;
+    P.released = e->d_released;
+    P.n_released = e->d_counters;
     P.chains = e->d_chains;
     P.pchains = e->d_pchains;
     P.q_rating = e->d_q_rating;
@@ -1477,9 +1481,9 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
         HIPCHK(e, hipGetLastError());
     }
     if (timing) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
-    const bool use_pair = M.team_size == 1u && M.teams == 2u && !purge && !e->force_generic;
+    const bool use_pair = M.team_size == 1u && M.teams == 2u && !e->force_generic;
     if (use_pair) {
-        int prc = pair_walk(e, mode, M);
+        int prc = pair_walk(e, mode, M, purge);
         if (prc) return prc;
     }
     WalkParams P;

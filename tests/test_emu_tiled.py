@@ -80,3 +80,34 @@ def test_forced_generic_walk(oracle_cls, monkeypatch):
     """MM_FORCE_GENERIC=1 walks 1v1 modes with k_walk as well (the A/B switch of the bench)."""
     monkeypatch.setenv("MM_FORCE_GENERIC", "1")
     two_ticks(oracle_cls, 3000, seed=10, window=40, regions=4)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_tiled_cancel_ticks_on_the_pair_path(oracle_cls, seed):
+    """Cancel ticks are walked by the pair path too: the open lobby's anchor, the head of the queue
+    and queued players are cancelled between ticks (stale-lobby rule of MATCH_CHECK.md §4), on
+    chains long enough for the tiled rounds."""
+    rng = np.random.default_rng(seed)
+    window = int(rng.choice([1, 5, 40]))
+    cfg = make_config([mode_1v1(window=window, region_filter=True)], capacity=16384)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        for k in range(4):
+            n = int(rng.choice([0, 1, 2, 300, 2500, 4000]))
+            rating = rng.integers(0, 1400, size=n).astype(np.int32)
+            cons = cons_make(0, rng.integers(0, 3, size=n), 0, 0)
+            assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+            cs = []
+            ls, _ = b.lobby_state(0, 0)
+            if len(ls) and rng.integers(0, 2):
+                cs += ls.tolist()
+            qs = b.queue_slots(0, 0)
+            if len(qs) and rng.integers(0, 2):
+                cs.append(int(qs[0]))
+            if len(qs) > 5:
+                cs += rng.choice(qs, size=3, replace=False).tolist()
+            if cs:
+                cs = np.unique(np.asarray(cs, np.uint32))
+                a.cancel(cs)
+                b.cancel(cs)
+            assert_same_tick(a.tick(0), b.tick(0), "seed %d tick %d" % (seed, k))
+            assert_same_state(a, b, cfg)
