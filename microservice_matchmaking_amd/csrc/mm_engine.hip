@@ -375,6 +375,8 @@ __global__ __launch_bounds__(256) void k_reset(uint32_t n_chains, ChainDev* __re
 
 struct PairChain;
 static __device__ __forceinline__ bool pair_chain_is_fast(const struct PairChain* pc, uint32_t g);
+struct TeamChain;
+static __device__ __forceinline__ bool team_chain_is_fast(const struct TeamChain* tc, uint32_t g);
 
 struct WalkParams {
     uint32_t mode, n_groups, capacity, purge;
@@ -394,6 +396,7 @@ struct WalkParams {
     float* out_score;          // [n_groups][out_rec_stride]
     uint32_t* out_pass;        // [n_groups][out_rec_stride]
     const struct PairChain* pskip;   // chains the pair path (mm_pair.inc) walks this tick, or NULL
+    const struct TeamChain* tskip;   // chains the team path (mm_team.inc) walked this tick, or NULL
 };
 
 // Discipline for the LDS lobby inside wave 0: every lane may READ it between two
@@ -572,6 +575,7 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = blockIdx.x;
     if (P.pskip && pair_chain_is_fast(P.pskip, g)) return;   // walked by the pair path
+    if (P.tskip && team_chain_is_fast(P.tskip, g)) return;   // walked by the team path
     const uint32_t c = P.mode * P.n_groups + g;
     const ModeDev& M = P.M;
     const size_t qo = (size_t)c * P.capacity;
@@ -844,10 +848,15 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
 }
 
 #include "mm_pair.inc"
+#include "mm_team.inc"
 
 static __device__ __forceinline__ bool pair_chain_is_fast(const struct PairChain* pc, uint32_t g)
 {
     return pc[g].fast != 0u;
+}
+static __device__ __forceinline__ bool team_chain_is_fast(const struct TeamChain* tc, uint32_t g)
+{
+    return tc[g].fast != 0u;
 }
 
 // ------------------------------------------------------------------------------------
@@ -902,6 +911,12 @@ struct mm_engine {
     bool pair_debug;           // MM_PAIR_DEBUG=1: print the pair path's diagnostics per tick
     uint32_t pair_tune;        // MM_PAIR_TUNE: PairParams.tune
     unsigned long long live_upper;   // upper bound of queued players (grid sizing)
+    // team path (mm_team.inc): shares the pair path's arrays, plus
+    TeamChain* d_tchains;
+    TeamChain* h_tchains;      // pinned
+    uint32_t* d_tk_chunk;      // [group][role][tk_chunk_stride]
+    uint32_t tk_chunk_stride;
+    uint32_t team_batch;       // MM_TEAM_BATCH: passes launched per host look at the chains
     // host
     ChainDev* h_chains;        // pinned, n_chains
     uint32_t* h_counters;      // pinned, 2
@@ -1055,6 +1070,8 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_out_score);
     (void)hipFree(e->d_out_pass);
     (void)hipFree(e->d_pchains);
+    (void)hipFree(e->d_tchains);
+    (void)hipFree(e->d_tk_chunk);
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(e->d_pk_key[b]); (void)hipFree(e->d_pk_oidx[b]);
         (void)hipFree(e->d_pk_nx16[b]); (void)hipFree(e->d_pk_bits[b]);
@@ -1066,6 +1083,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); }
     (void)hipFree(e->d_pk_tilectl);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
+    if (e->h_tchains) (void)hipHostFree(e->h_tchains);
     if (e->h_rslots) (void)hipHostFree(e->h_rslots);
     if (e->h_rscore) (void)hipHostFree(e->h_rscore);
     if (e->h_rpass) (void)hipHostFree(e->h_rpass);
@@ -1122,6 +1140,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         const char* pb = getenv("MM_PAIR_BATCH");
         e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 32u;
         if (e->pair_batch < 1u) e->pair_batch = 1u;
+        const char* tb = getenv("MM_TEAM_BATCH");
+        e->team_batch = tb ? (uint32_t)strtoul(tb, NULL, 0) : 16u;
+        if (e->team_batch < 1u) e->team_batch = 1u;
     }
     const size_t cap = cfg->capacity;
 #define CREATE_CHK(call)                                                 \
@@ -1177,6 +1198,11 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         CREATE_CHK(hipHostMalloc((void**)&e->h_rscore, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(float), hipHostMallocDefault));
         CREATE_CHK(hipHostMalloc((void**)&e->h_rpass, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
         CREATE_CHK(hipMemsetAsync(e->d_pchains, 0, cfg->n_groups * sizeof(PairChain), e->stream));
+        e->tk_chunk_stride = (uint32_t)(e->pk_stride / TT_CH + 2);
+        CREATE_CHK(hipMalloc((void**)&e->d_tchains, cfg->n_groups * sizeof(TeamChain)));
+        CREATE_CHK(hipMalloc((void**)&e->d_tk_chunk, (size_t)cfg->n_groups * MM_MAX_ROLES * e->tk_chunk_stride * sizeof(uint32_t)));
+        CREATE_CHK(hipHostMalloc((void**)&e->h_tchains, cfg->n_groups * sizeof(TeamChain), hipHostMallocDefault));
+        CREATE_CHK(hipMemsetAsync(e->d_tchains, 0, cfg->n_groups * sizeof(TeamChain), e->stream));
     }
     CREATE_CHK(hipHostMalloc((void**)&e->h_chains, e->n_chains * sizeof(ChainDev), hipHostMallocDefault));
     CREATE_CHK(hipHostMalloc((void**)&e->h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault));
@@ -1461,6 +1487,86 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     return MM_OK;
 }
 
+// The team path (mm_team.inc).  *any is set when at least one chain was walked by it; the others
+// are left to k_walk.
+static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
+{
+    const mm_config& cfg = e->cfg;
+    const uint32_t G = cfg.n_groups;
+    *any = false;
+    TeamParams P;
+    memset(&P, 0, sizeof(P));
+    P.mode = mode;
+    P.n_groups = G;
+    P.capacity = cfg.capacity;
+    P.window = M.window > 0xFFFFFu ? 0xFFFFFu : M.window;
+    P.eqmask = M.eqmask;
+    P.out_cap = (cfg.capacity + MM_MAX_LOBBY) / M.L + 1u;
+    P.out_slot_stride = e->out_slot_stride;
+    P.out_rec_stride = e->out_rec_stride;
+    P.bits_stride = e->pk_bits_stride;
+    P.pstride = e->pk_stride;
+    P.chunk_stride = e->tk_chunk_stride;
+    P.blk_stride = e->pk_stride / 64u;
+    P.M = M;
+    P.chains = e->d_chains;
+    P.tchains = e->d_tchains;
+    P.q_rating = e->d_q_rating;
+    P.q_cons = e->d_q_cons;
+    P.q_slot = e->d_q_slot;
+    P.tkey = e->d_pk_key[0];
+    P.bits[0] = e->d_pk_bits[0];
+    P.bits[1] = e->d_pk_bits[1];
+    P.sqk = e->d_pk_key[1];
+    P.sqp = e->d_pk_oidx[0];
+    P.fv = e->d_pk_scratch;
+    P.vis = e->d_pk_rec1;
+    P.blkbase = e->d_pk_oidx[1];
+    P.chunk = e->d_tk_chunk;
+    P.out_slots = e->d_out_slots;
+    P.out_score = e->d_out_score;
+    P.out_pass = e->d_out_pass;
+    hipLaunchKernelGGL(kt_init, dim3(G), dim3(1024), 0, e->stream, P);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(e->h_tchains, e->d_tchains, G * sizeof(TeamChain), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    uint32_t longest = 0;
+    for (uint32_t g = 0; g < G; ++g)
+        if (e->h_tchains[g].fast && e->h_tchains[g].m > longest) longest = e->h_tchains[g].m;
+    if (!longest) return MM_OK;
+    *any = true;
+    const uint32_t nch = (longest + TT_CH - 1u) / TT_CH;
+    uint32_t ex = longest / (M.L * TE_WAVES * 2u) + 1u;
+    if (ex > 256u) ex = 256u;
+    hipLaunchKernelGGL(kt_pack, dim3(nch, G), dim3(1024), 0, e->stream, P);
+    HIPCHK(e, hipGetLastError());
+    for (uint32_t guard = 0;; ++guard) {
+        // a pass that changes nothing ends a chain and every other pass seats somebody
+        if (guard > cfg.capacity / e->team_batch + 64u) return MM_ERR_INTERNAL;
+        for (uint32_t b = 0; b < e->team_batch; ++b) {
+            hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(1024), 0, e->stream, P);
+            hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(1024), 0, e->stream, P);
+            hipLaunchKernelGGL(kt_chase, dim3(G), dim3(64), 0, e->stream, P);
+            hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
+        }
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipMemcpyAsync(e->h_tchains, e->d_tchains, G * sizeof(TeamChain), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        bool busy = false;
+        for (uint32_t g = 0; g < G; ++g)
+            if (e->h_tchains[g].fast && !e->h_tchains[g].done) busy = true;
+        if (!busy) break;
+    }
+    hipLaunchKernelGGL(kt_fin_scatter, dim3(nch, G), dim3(1024), 0, e->stream, P);
+    hipLaunchKernelGGL(kt_fin_copy, dim3(nch, G), dim3(1024), 0, e->stream, P);
+    HIPCHK(e, hipGetLastError());
+    if (e->pair_debug)
+        for (uint32_t g = 0; g < G; ++g)
+            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u\n", g, e->h_tchains[g].fast,
+                    e->h_tchains[g].m, e->h_tchains[g].passes, e->h_tchains[g].n_out, e->h_tchains[g].qlen);
+    return MM_OK;
+}
+
 extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats)
 {
     if (!e || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
@@ -1486,6 +1592,12 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
         int prc = pair_walk(e, mode, M, purge);
         if (prc) return prc;
     }
+    // team modes: long chains of a tick without pending cancels take the team path
+    bool team_any = false;
+    if (!use_pair && !e->force_generic && !purge && e->live_upper >= TT_MIN) {
+        int trc = team_walk(e, mode, M, &team_any);
+        if (trc) return trc;
+    }
     WalkParams P;
     memset(&P, 0, sizeof(P));
     P.mode = mode;
@@ -1508,6 +1620,7 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
     P.out_score = e->d_out_score;
     P.out_pass = e->d_out_pass;
     P.pskip = use_pair ? e->d_pchains : NULL;
+    P.tskip = team_any ? e->d_tchains : NULL;
     hipLaunchKernelGGL(k_walk, dim3(G), dim3(WK_THREADS), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
     if (timing) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
@@ -1524,12 +1637,9 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
                     hp[g].dbg[2], hp[g].dbg[3], hp[g].dbg[4], hp[g].dbg[5], hp[g].dbg[6], hp[g].dbg[7]);
         for (uint32_t g = 0; g < G; ++g)
             if (hp[g].rounds)
-                fprintf(stderr, "[mm-pair] g%u tile1 cycles/round: prep load %u fix %u (items %.1f, pass1 %u) build %u doubling %u (rounds %.1f) publish %u | route head %u hops %u | apply load %u chase %u (steps %.1f) emit %u\n",
-                        g, hp[g].tm[0] / hp[g].rounds, hp[g].tm[1] / hp[g].rounds, (double)hp[g].tm[12] / hp[g].rounds,
-                        hp[g].tm[13] / hp[g].rounds, hp[g].tm[2] / hp[g].rounds,
-                        hp[g].tm[3] / hp[g].rounds, (double)hp[g].tm[5] / hp[g].rounds, hp[g].tm[4] / hp[g].rounds,
-                        hp[g].tm[6] / hp[g].rounds, hp[g].tm[7] / hp[g].rounds, hp[g].tm[8] / hp[g].rounds,
-                        hp[g].tm[9] / hp[g].rounds, (double)hp[g].tm[11] / hp[g].rounds, hp[g].tm[10] / hp[g].rounds);
+                fprintf(stderr, "[mm-pair] g%u tile1 cycles/round (fused: load %u walk+stage %u apply %u | repair %u build %u resolve %u publish+head %u)\n",
+                        g, hp[g].tm[0] / hp[g].rounds, hp[g].tm[6] / hp[g].rounds, hp[g].tm[9] / hp[g].rounds,
+                        hp[g].tm[1] / hp[g].rounds, hp[g].tm[2] / hp[g].rounds, hp[g].tm[3] / hp[g].rounds, hp[g].tm[4] / hp[g].rounds);
     }
 
     uint32_t total = 0, after = 0, before = 0, pmax = 0, errf = 0;

@@ -18,9 +18,70 @@ from microservice_matchmaking_amd import Engine, cons_make, make_config, mode_1v
 from oracle.oracle import OracleEngine  # noqa: E402
 
 
+def random_team_mode(rng):
+    """A team mode the config validator accepts: teams * team_size <= 16, quotas sum to team_size."""
+    teams = int(rng.choice([2, 2, 2, 3, 4]))
+    team_size = int(rng.integers(1 if teams > 2 else 2, 16 // teams + 1))
+    team_size = min(team_size, 8)
+    n_roles = int(rng.integers(1, min(team_size, 5) + 1))
+    quota = np.ones(n_roles, np.int64)
+    for _ in range(team_size - n_roles):
+        quota[rng.integers(0, n_roles)] += 1
+    window = int(rng.choice([5, 25, 50, 150, 600, 10 ** 6]))
+    return mode_team(team_size, teams, window, tuple(int(q) for q in quota),
+                     region_filter=bool(rng.integers(0, 3) == 0), party_filter=bool(rng.integers(0, 5) == 0))
+
+
+def team_main(budget, seed0):
+    """Team modes only: long chains take mm_team.inc, short ones and cancel ticks k_walk."""
+    t_end = time.time() + budget
+    n_done = 0
+    k = 0
+    while time.time() < t_end:
+        seed = seed0 * 100003 + k
+        k += 1
+        rng = np.random.default_rng(seed)
+        modes = [random_team_mode(rng)]
+        nr = modes[0]["n_roles"]
+        cfg = make_config(modes, capacity=1 << 18, timing=False)
+        regions = int(rng.choice([1, 2, 8])) if modes[0]["region_filter"] else 1
+        parties = 3 if modes[0]["party_filter"] else 1
+        lo = int(rng.choice([0, 0, 1000, 2400]))
+        hi = int(rng.choice([1499, 2600, 5000, 5000]))
+        if hi <= lo:
+            hi = lo + 600
+        w = rng.random(nr) + 0.05
+        w /= w.sum()
+        sizes = [int(rng.choice([3000, 20000, 60000, 120000]))] + \
+                [int(rng.choice([0, 100, 5000, 30000])) for _ in range(int(rng.integers(0, 4)))]
+        tag = "team seed %d mode=%s ratings=[%d,%d] sizes=%s" % (seed, modes[0], lo, hi, sizes)
+        with Engine(cfg) as a, OracleEngine(cfg) as b:
+            live = np.zeros(0, np.uint32)
+            for j, n in enumerate(sizes):
+                rating = rng.integers(lo, hi + 1, size=n).astype(np.int32)
+                cons = cons_make(0, rng.integers(0, regions, size=n), rng.integers(0, parties, size=n),
+                                 rng.choice(nr, size=n, p=w))
+                sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+                assert np.array_equal(sa, sb), tag
+                live = np.concatenate([live, sa])
+                if live.size > 10 and rng.integers(0, 4) == 0:
+                    cs = rng.choice(live, size=max(1, live.size // 50), replace=False)
+                    a.cancel(cs)
+                    b.cancel(cs)
+                    live = np.setdiff1d(live, cs)
+                ma, mb = a.tick(0), b.tick(0)
+                assert_same_tick(ma, mb, tag + " tick %d" % j)
+                live = np.setdiff1d(live, ma.slots.ravel())
+                assert_same_state(a, b, cfg, tag)
+        n_done += 1
+    print("gpu_stress team: %d scenarios ok (seeds %d..%d)" % (n_done, seed0 * 100003, seed0 * 100003 + k - 1))
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "team":
+        return team_main(budget, seed0)
     t_end = time.time() + budget
     n_done = 0
     k = 0
