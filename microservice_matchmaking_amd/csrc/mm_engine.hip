@@ -917,6 +917,7 @@ struct mm_engine {
     uint32_t* d_tk_chunk;      // [group][role][tk_chunk_stride]
     uint32_t tk_chunk_stride;
     uint32_t team_batch;       // MM_TEAM_BATCH: passes launched per host look at the chains
+    uint32_t team_cap;         // MM_TEAM_CAP: TeamParams.scan_cap
     // host
     ChainDev* h_chains;        // pinned, n_chains
     uint32_t* h_counters;      // pinned, 2
@@ -1143,6 +1144,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         const char* tb = getenv("MM_TEAM_BATCH");
         e->team_batch = tb ? (uint32_t)strtoul(tb, NULL, 0) : 16u;
         if (e->team_batch < 1u) e->team_batch = 1u;
+        const char* tcap = getenv("MM_TEAM_CAP");
+        e->team_cap = tcap ? (uint32_t)strtoul(tcap, NULL, 0) : TT_SCAN_CAP;
+        if (e->team_cap < 1u) e->team_cap = 1u;
     }
     const size_t cap = cfg->capacity;
 #define CREATE_CHK(call)                                                 \
@@ -1508,6 +1512,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
     P.pstride = e->pk_stride;
     P.chunk_stride = e->tk_chunk_stride;
     P.blk_stride = e->pk_stride / 64u;
+    P.scan_cap = e->team_cap;
+    P.debug = e->pair_debug ? 1u : 0u;
     P.M = M;
     P.chains = e->d_chains;
     P.tchains = e->d_tchains;
@@ -1546,7 +1552,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
         for (uint32_t b = 0; b < e->team_batch; ++b) {
             hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(1024), 0, e->stream, P);
             hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(1024), 0, e->stream, P);
-            hipLaunchKernelGGL(kt_chase, dim3(G), dim3(64), 0, e->stream, P);
+            hipLaunchKernelGGL(kt_chase, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
             hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
         }
         HIPCHK(e, hipGetLastError());
@@ -1562,8 +1568,10 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
     HIPCHK(e, hipGetLastError());
     if (e->pair_debug)
         for (uint32_t g = 0; g < G; ++g)
-            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u\n", g, e->h_tchains[g].fast,
-                    e->h_tchains[g].m, e->h_tchains[g].passes, e->h_tchains[g].n_out, e->h_tchains[g].qlen);
+            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | kt_f chunk 1 cycles/pass: stage %u scan(wave 0) %u scan(workgroup) %u tail %u\n", g, e->h_tchains[g].fast,
+                    e->h_tchains[g].m, e->h_tchains[g].passes, e->h_tchains[g].n_out, e->h_tchains[g].qlen,
+                    e->h_tchains[g].dbg[0] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[1] / (e->h_tchains[g].passes + 1u),
+                    e->h_tchains[g].dbg[2] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[3] / (e->h_tchains[g].passes + 1u));
     return MM_OK;
 }
 
