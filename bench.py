@@ -219,7 +219,7 @@ def main():
 
     if rank == 0:
         walk_name = ("pair walk: kp_nx_init + kp_round x rounds + kp_late + kp_finish"
-                     if args.mode == "1v1" else "k_walk")
+                     if args.mode == "1v1" else "team walk: (kt_build + kt_f + kt_chase + kt_emit) x passes")
         k_ms = float(np.mean(walk_ms))
         achieved = pairs * bytes_per_pair / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
@@ -256,10 +256,14 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": pairs * bytes_per_pair,
                          "launch": "one tick = one walk to quiescence (HIP events around the kernel sequence)",
-                         "note": "Mode R is a chain of dependent first-fit steps (%d passes of the cursor for "
-                                 "the longest rating group); the engine replaces the per-pair rescans by "
-                                 "next[] pointers repaired incrementally, so it is bound by pass latency "
-                                 "(kernel boundaries + LDS/VALU issue), not by HBM; see DESIGN.md" % last.stats["passes_max"]},
+                         "note": ("Mode R is a chain of dependent first-fit steps (%d passes of the cursor for "
+                                  "the longest rating group); the engine replaces the per-pair rescans by "
+                                  "%s, so it is bound by pass latency (kernel boundaries + LDS/VALU issue), "
+                                  "not by HBM; see DESIGN.md") % (
+                                     last.stats["passes_max"],
+                                     "next[] pointers repaired incrementally" if args.mode == "1v1" else
+                                     "per-pass F pointers (who the cursor picks after each player's lobby) "
+                                     "computed for every queued player at once")},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, rating, cons, args.mode)

@@ -29,6 +29,9 @@
 //   mm_pair.inc   the 1v1 walk: next[] pointers for every queued player, one launch per pass
 //           over all tiles of all chains (kp_round), an LDS-resident speculative pointer chase
 //           for short chains (kp_late).  DESIGN.md §4.3.
+//   mm_team.inc   the team-mode walk: per pass, role sub-queues and F[a] = the player the
+//           cursor picks after a's lobby, for every queued a at once, then a pointer chase
+//           (kt_build / kt_f / kt_chase / kt_emit).  DESIGN.md §4.4.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
