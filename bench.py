@@ -94,54 +94,76 @@ def cpu_baseline(cfg, rating, cons, mode_name, budget_s=20.0):
     }
 
 
-def stream_latency(make_engine, qps, seconds, tick_ms, window, seed=77):
+def stream_latency(make_engine, qps, seconds, tick_ms, label, seed=77, mode_weights=None, role_weights=None):
     """Second half of BASELINE.json's metric: match latency at a fixed enqueue rate.  Players
     arrive as a Poisson stream (`qps`), every `tick_ms` of REAL time the arrivals of the period
-    are enqueued (host pointers, so the H2D copy and the bucketing kernels are inside) and one
-    tick is run; a matched player's latency = wall time at which its lobby came back from
-    mm_tick minus its arrival time.  Reported: p50 / p99 / max, matched players/s, backlog."""
+    are enqueued (host pointers, so the H2D copy and the bucketing kernels are inside) and every
+    mode is ticked once; a matched player's latency = wall time at which its lobby came back
+    from mm_tick minus its arrival time.  Reported: p50 / p99 / max, matched players/s, backlog.
+    `mode_weights` mixes the engine's modes (BASELINE cfg-5: 70 % 1v1 / 30 % 5v5); players of
+    mode 1 draw a role from `role_weights`."""
     import time as _t
     from microservice_matchmaking_amd.synth import make_pool
     eng = make_engine()
+    n_modes = int(eng.cfg.n_modes)
     rng = np.random.default_rng(seed)
     n_ticks = int(seconds * 1000.0 / tick_ms)
     arrival = np.zeros(eng.cfg.capacity, dtype=np.float64)     # by slot
-    lat, tick_cost = [], []
+    lat = [[] for _ in range(n_modes)]
+    tick_cost = []
     matched = 0
+
+    def batch(n, sd):
+        rating, cons = make_pool(n, seed=sd, mode_weights=mode_weights, role_weights=role_weights)
+        if mode_weights:
+            cons = np.where((cons & 0xF) == 0, cons & ~np.uint32(0xF << 16), cons).astype(np.uint32)
+        return rating, cons
+
     # warm the kernels up outside the clock
-    r0, c0 = make_pool(2000, seed=seed)
+    r0, c0 = batch(2000, seed)
     eng.enqueue(r0, c0)
-    eng.tick(0)
+    for md in range(n_modes):
+        eng.tick(md)
     eng.reset()
     t_start = _t.perf_counter()
     for k in range(n_ticks):
         t_open, t_close = k * tick_ms * 1e-3, (k + 1) * tick_ms * 1e-3
         n = int(rng.poisson(qps * tick_ms * 1e-3))
-        rating, cons = make_pool(n, seed=seed + 1 + k)
+        rating, cons = batch(n, seed + 1 + k)
         ts = np.sort(rng.uniform(t_open, t_close, size=n))
         while _t.perf_counter() - t_start < t_close:            # the period has to be over
             pass
         t0 = _t.perf_counter()
         slots = eng.enqueue(rating, cons)
         arrival[slots] = ts
-        m = eng.tick(0)
-        t1 = _t.perf_counter()
-        tick_cost.append(t1 - t0)
-        if len(m):
-            s_ = m.slots.ravel()
-            lat.append((t1 - t_start) - arrival[s_])
-            matched += s_.size
+        for md in range(n_modes):
+            m = eng.tick(md)
+            t1 = _t.perf_counter()
+            if len(m):
+                s_ = m.slots.ravel()
+                lat[md].append((t1 - t_start) - arrival[s_])
+                matched += s_.size
+        tick_cost.append(_t.perf_counter() - t0)
     elapsed = _t.perf_counter() - t_start
-    depth = int(eng.queue_depth(0).sum())
+    depth = [int(eng.queue_depth(md).sum()) for md in range(n_modes)]
     eng.close()
-    lat = np.concatenate(lat) if lat else np.zeros(1)
-    return {"enqueue_qps": qps, "tick_ms": tick_ms, "seconds": seconds, "mode": "1v1 +-%d, region filter" % window,
-            "p50_ms": float(np.percentile(lat, 50) * 1e3), "p99_ms": float(np.percentile(lat, 99) * 1e3),
-            "max_ms": float(lat.max() * 1e3), "matched_players_per_s": matched / elapsed,
-            "tick_cost_ms_mean": float(np.mean(tick_cost) * 1e3), "tick_cost_ms_p99": float(np.percentile(tick_cost, 99) * 1e3),
-            "backlog_players": depth, "kept_up": bool(elapsed < seconds * 1.05),
-            "note": "latency floor = half a tick period + the tick; a chain whose anchor nobody fits waits for "
-                    "arrivals (reference behaviour, docs/MATCH_CHECK.md section 4)"}
+    per_mode = []
+    for md in range(n_modes):
+        v = np.concatenate(lat[md]) if lat[md] else np.zeros(1)
+        per_mode.append({"p50_ms": float(np.percentile(v, 50) * 1e3), "p99_ms": float(np.percentile(v, 99) * 1e3),
+                         "max_ms": float(v.max() * 1e3), "matched_players": int(v.size if lat[md] else 0),
+                         "backlog_players": depth[md]})
+    allv = np.concatenate([np.concatenate(x) for x in lat if x]) if any(lat) else np.zeros(1)
+    out = {"enqueue_qps": qps, "tick_ms": tick_ms, "seconds": seconds, "mode": label,
+           "p50_ms": float(np.percentile(allv, 50) * 1e3), "p99_ms": float(np.percentile(allv, 99) * 1e3),
+           "max_ms": float(allv.max() * 1e3), "matched_players_per_s": matched / elapsed,
+           "tick_cost_ms_mean": float(np.mean(tick_cost) * 1e3), "tick_cost_ms_p99": float(np.percentile(tick_cost, 99) * 1e3),
+           "backlog_players": int(sum(depth)), "kept_up": bool(elapsed < seconds * 1.05),
+           "note": "latency floor = half a tick period + the tick; a chain whose anchor nobody fits waits for "
+                   "arrivals (reference behaviour, docs/MATCH_CHECK.md section 4)"}
+    if n_modes > 1:
+        out["per_mode"] = per_mode
+    return out
 
 
 def main():
@@ -270,7 +292,14 @@ def main():
         if world == 1 and not args.no_stream and args.mode == "1v1":
             scfg = make_config(modes, capacity=1 << 20, device=local_rank, timing=False)
             line["latency"] = stream_latency(lambda: Engine(scfg), args.stream_qps, args.stream_seconds,
-                                             args.stream_tick_ms, args.window)
+                                             args.stream_tick_ms, "1v1 +-%d, region filter" % args.window)
+            # BASELINE cfg-5 on one GPU: the same stream with 70 % 1v1 / 30 % 5v5 (roles as cfg-3)
+            mcfg = make_config([mode_1v1(window=args.window, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
+                               capacity=1 << 20, device=local_rank, timing=False)
+            line["latency_mixed"] = stream_latency(lambda: Engine(mcfg), args.stream_qps, args.stream_seconds,
+                                                   args.stream_tick_ms,
+                                                   "70 %% 1v1 +-%d region filter / 30 %% 5v5 +-50 five roles" % args.window,
+                                                   mode_weights=(70, 30), role_weights=ROLE_WEIGHTS_5V5)
         print(json.dumps(line), flush=True)
     eng.close()
     if dist_on:

@@ -84,7 +84,7 @@ def test_team_short_chains_stay_with_k_walk(oracle_cls):
     same tick are walked by k_walk."""
     cfg = make_config([mode_team(2, 2, 150, (1, 1))], capacity=16384)
     rng = np.random.default_rng(8)
-    n = 6000
+    n = 5200
     rating = np.where(rng.random(n) < 0.8, rng.integers(0, 1500, size=n), rng.integers(1500, 5001, size=n)).astype(np.int32)
     cons = cons_make(0, 0, 0, rng.integers(0, 2, size=n))
     with EmuEngine(cfg) as a, oracle_cls(cfg) as b:
