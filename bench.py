@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--stream-qps", type=int, default=100_000)
     ap.add_argument("--stream-seconds", type=float, default=3.0)
     ap.add_argument("--stream-tick-ms", type=float, default=10.0)
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+    ap.add_argument("--traffic-json", default=None,
                     help="optional {'k_walk_hbm_bytes_per_launch': ...} from a rocprofv3 --pmc pass")
     return ap.parse_args()
 
@@ -246,7 +246,9 @@ def main():
         achieved = pairs * bytes_per_pair / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         try:
-            with open(args.traffic_json) as f:
+            tpath = args.traffic_json or os.path.join(
+                ROOT, "profiles", "traffic_latest.json" if args.mode == "1v1" else "traffic_latest_%s.json" % args.mode)
+            with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("workload_players") == n and tj.get("mode") == args.mode:
                 traffic = tj.get("walk_hbm_bytes_per_tick")

@@ -219,6 +219,54 @@ def test_gpu_pair_path_multi_tick_with_cancels(gpu_cls, oracle_cls):
             live = np.setdiff1d(live, ma.slots.ravel())
 
 
+TEAM_VARIANTS = {
+    "2v2_one_role": (mode_team(2, 2, 100, (2,)), None, 1),
+    "3teams_region": (mode_team(2, 3, 400, (1, 1), region_filter=True), (50, 50), 4),
+    "4v4_uneven_quota": (mode_team(4, 2, 150, (2, 1, 1)), (20, 40, 40), 1),
+    "8v8_full_width": (mode_team(8, 2, 300, (2, 2, 2, 2)), (25, 25, 25, 25), 1),
+    "5v5_narrow_party": (mode_team(5, 2, 20, (1, 1, 1, 1, 1), party_filter=True), (15, 15, 30, 30, 10), 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(TEAM_VARIANTS))
+def test_gpu_team_path_variants(gpu_cls, oracle_cls, name):
+    """The team path (mm_team.inc) across lobby shapes: three ticks with arrivals (stored lobbies
+    carry over), then a cancel tick (generic kernel) and a tick after it."""
+    mode, role_w, regions = TEAM_VARIANTS[name]
+    cfg = make_config([mode], capacity=1 << 19)
+    rng = np.random.default_rng(5)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        live = np.zeros(0, np.uint32)
+        for k, n in enumerate([200000, 60000, 3000, 40000, 80000]):
+            rating, cons = make_pool(n, seed=60 + k, dist="normal" if k == 1 else "uniform", n_regions=regions,
+                                     role_weights=role_w, party_max=3 if mode["party_filter"] else 1)
+            sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+            assert np.array_equal(sa, sb)
+            live = np.concatenate([live, sa])
+            if k == 3:
+                cs = rng.choice(live, size=2000, replace=False)
+                a.cancel(cs)
+                b.cancel(cs)
+                live = np.setdiff1d(live, cs)
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "%s tick %d" % (name, k), SCORE_TOL)
+            assert_same_state(a, b, cfg, "%s tick %d" % (name, k))
+            live = np.setdiff1d(live, ma.slots.ravel())
+
+
+@pytest.mark.parametrize("cap", [1, 16, 100000])
+def test_gpu_team_scan_horizon(gpu_cls, oracle_cls, monkeypatch, cap):
+    """MM_TEAM_CAP: with a horizon of one sub-queue entry every lobby is worked out by kt_chase's
+    wave-wide scan; with none every scan runs to the end of its sub-queue.  Same lobbies."""
+    monkeypatch.setenv("MM_TEAM_CAP", str(cap))
+    cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 17)
+    rating, cons = make_pool(100000, seed=9, role_weights=ROLE_WEIGHTS_5V5)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+        assert_same_tick(a.tick(0), b.tick(0), "cap %d" % cap, SCORE_TOL)
+        assert_same_state(a, b, cfg)
+
+
 def test_gpu_1v1_10m_pool(gpu_cls, oracle_cls):
     """BASELINE cfg-4 on one device: 10M players, 1v1 +-25 + region filter (chains of 1-3M players,
     hundreds of tiles per chain).  On a node the same chains spread over the ranks by rating group
