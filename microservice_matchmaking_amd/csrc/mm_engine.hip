@@ -1547,14 +1547,14 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
     const uint32_t nch = (longest + TT_CH - 1u) / TT_CH;
     uint32_t ex = longest / (M.L * TE_WAVES * 2u) + 1u;
     if (ex > 256u) ex = 256u;
-    hipLaunchKernelGGL(kt_pack, dim3(nch, G), dim3(1024), 0, e->stream, P);
+    hipLaunchKernelGGL(kt_pack, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
     for (uint32_t guard = 0;; ++guard) {
         // a pass that changes nothing ends a chain and every other pass seats somebody
         if (guard > cfg.capacity / e->team_batch + 64u) return MM_ERR_INTERNAL;
         for (uint32_t b = 0; b < e->team_batch; ++b) {
-            hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(1024), 0, e->stream, P);
-            hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(1024), 0, e->stream, P);
+            hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+            hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
             hipLaunchKernelGGL(kt_chase, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
             hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
         }
@@ -1566,8 +1566,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
             if (e->h_tchains[g].fast && !e->h_tchains[g].done) busy = true;
         if (!busy) break;
     }
-    hipLaunchKernelGGL(kt_fin_scatter, dim3(nch, G), dim3(1024), 0, e->stream, P);
-    hipLaunchKernelGGL(kt_fin_copy, dim3(nch, G), dim3(1024), 0, e->stream, P);
+    hipLaunchKernelGGL(kt_fin_scatter, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+    hipLaunchKernelGGL(kt_fin_copy, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
     if (e->pair_debug)
         for (uint32_t g = 0; g < G; ++g)
