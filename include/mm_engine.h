@@ -222,6 +222,27 @@ int mm_queue_depth(mm_engine* e, uint32_t mode, uint32_t* per_group);
 int mm_lobby_state(mm_engine* e, uint32_t mode, uint32_t group, uint32_t* n,
                    uint32_t* slots, uint8_t* teams);
 
+/* ---- pool snapshot -------------------------------------
+ * The reference keeps everything this engine holds in RAM-only tables and unacked broker
+ * deliveries: `LobbyState` is `ram_copies` (lib/models/lobby_state.ex:19-26), `ActiveUser`
+ * likewise (lib/models/active_user.ex:15-29), the queues live in the broker.  A restart of
+ * the search stage therefore rebuilds its state by redelivery.  With the engine in between,
+ * a restart of the BEAM node (or a move to another GPU) dumps and reloads the pool instead:
+ * queues in order, stored lobbies, the ActiveUser mirror, the slot allocator.  The results
+ * of the last tick (mm_matches) are not part of a snapshot.
+ *
+ * mm_snapshot_size: bytes mm_snapshot would write now.
+ * mm_snapshot:      writes the snapshot into buf (cap bytes); *written = its size.
+ *                   MM_ERR_RANGE if cap is too small.
+ * mm_restore:       replaces the engine's whole state with the snapshot's.  The engine must
+ *                   have been created with the same mm_config (groups, modes, capacity):
+ *                   MM_ERR_INVALID_ARG otherwise, and for a damaged or truncated buffer
+ *                   (checksummed) — the engine's state is untouched then.  A HIP failure
+ *                   during the reload leaves the engine reset, never half restored. */
+int mm_snapshot_size(mm_engine* e, uint64_t* bytes);
+int mm_snapshot(mm_engine* e, void* buf, uint64_t cap, uint64_t* written);
+int mm_restore(mm_engine* e, const void* buf, uint64_t bytes);
+
 /* Last HIP error code seen by this engine (0 if none) — for logs, never for control flow. */
 int mm_last_hip_error(const mm_engine* e);
 

@@ -120,6 +120,14 @@ def bind(lib, prefix):
     f("queue_depth").restype = C.c_int
     f("lobby_state").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p, C.c_void_p, C.c_void_p]
     f("lobby_state").restype = C.c_int
+    if hasattr(lib, prefix + "snapshot"):                 # the oracle does not mirror these
+        u64p = C.POINTER(C.c_uint64)
+        f("snapshot_size").argtypes = [C.c_void_p, u64p]
+        f("snapshot_size").restype = C.c_int
+        f("snapshot").argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, u64p]
+        f("snapshot").restype = C.c_int
+        f("restore").argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        f("restore").restype = C.c_int
     return lib
 
 
@@ -227,6 +235,19 @@ class EngineBase:
         out = np.zeros(self.cfg.n_groups, dtype=np.uint32)
         self._check(self._fn("queue_depth")(self._h, mode, _ptr(out)), "queue_depth")
         return out
+
+    def snapshot(self) -> bytes:
+        """The whole pool (queues in order, stored lobbies, ActiveUser mirror, slot allocator)."""
+        n = C.c_uint64()
+        self._check(self._fn("snapshot_size")(self._h, C.byref(n)), "snapshot_size")
+        buf = np.empty(int(n.value), dtype=np.uint8)
+        w = C.c_uint64()
+        self._check(self._fn("snapshot")(self._h, _ptr(buf), C.c_uint64(buf.size), C.byref(w)), "snapshot")
+        return buf[:int(w.value)].tobytes()
+
+    def restore(self, blob: bytes):
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        self._check(self._fn("restore")(self._h, _ptr(buf), C.c_uint64(buf.size)), "restore")
 
     def lobby_state(self, mode, group):
         n = C.c_uint32()

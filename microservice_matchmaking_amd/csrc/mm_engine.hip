@@ -1765,4 +1765,150 @@ extern "C" int mm_lobby_state(mm_engine* e, uint32_t mode, uint32_t group, uint3
     return MM_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// pool snapshot / restore
+// ------------------------------------------------------------------------------------
+struct SnapHeader {
+    uint32_t magic, version, abi, header_bytes;
+    uint32_t capacity, n_groups, n_modes, n_chains;
+    uint32_t next_slot, cancel_pending, chain_bytes, reserved;
+    unsigned long long live_upper, cfg_hash, payload_hash, total_bytes;
+};
+#define MM_SNAP_MAGIC 0x4E534D4Du   /* "MMSN" */
+
+static unsigned long long snap_hash(const void* p, size_t n, unsigned long long h)
+{
+    const unsigned char* b = (const unsigned char*)p;   // FNV-1a, 64 bit
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001B3ull; }
+    return h;
+}
+
+static unsigned long long snap_cfg_hash(const mm_config& c)
+{
+    unsigned long long h = 0xCBF29CE484222325ull;
+    h = snap_hash(&c.n_groups, sizeof(c.n_groups), h);
+    h = snap_hash(c.groups, sizeof(mm_rating_group) * c.n_groups, h);
+    h = snap_hash(&c.default_group, sizeof(c.default_group), h);
+    h = snap_hash(&c.n_modes, sizeof(c.n_modes), h);
+    for (uint32_t m = 0; m < c.n_modes; ++m) {
+        const mm_mode_config& mc = c.modes[m];
+        h = snap_hash(&mc.team_size, sizeof(mc.team_size), h);
+        h = snap_hash(&mc.teams, sizeof(mc.teams), h);
+        h = snap_hash(&mc.window, sizeof(mc.window), h);
+        h = snap_hash(&mc.flags, sizeof(mc.flags), h);
+        h = snap_hash(&mc.n_roles, sizeof(mc.n_roles), h);
+        h = snap_hash(mc.role_quota, mc.n_roles, h);
+    }
+    h = snap_hash(&c.capacity, sizeof(c.capacity), h);
+    return h;
+}
+
+extern "C" int mm_snapshot_size(mm_engine* e, uint64_t* bytes)
+{
+    if (!e || !bytes) return MM_ERR_INVALID_ARG;
+    int rc = fetch_chains(e);
+    if (rc) return rc;
+    uint64_t n = sizeof(SnapHeader) + e->cfg.capacity + (uint64_t)e->n_chains * sizeof(ChainDev);
+    for (uint32_t c = 0; c < e->n_chains; ++c) n += (uint64_t)e->h_chains[c].len * 12u;
+    *bytes = n;
+    return MM_OK;
+}
+
+extern "C" int mm_snapshot(mm_engine* e, void* buf, uint64_t cap, uint64_t* written)
+{
+    if (!e || !buf || !written) return MM_ERR_INVALID_ARG;
+    uint64_t need = 0;
+    int rc = mm_snapshot_size(e, &need);                  // also refreshes h_chains
+    if (rc) return rc;
+    if (cap < need) return MM_ERR_RANGE;
+    unsigned char* out = (unsigned char*)buf;
+    SnapHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = MM_SNAP_MAGIC;
+    h.version = 1;
+    h.abi = MM_ABI_VERSION;
+    h.header_bytes = (uint32_t)sizeof(SnapHeader);
+    h.capacity = e->cfg.capacity;
+    h.n_groups = e->cfg.n_groups;
+    h.n_modes = e->cfg.n_modes;
+    h.n_chains = e->n_chains;
+    h.next_slot = e->next_slot;
+    h.cancel_pending = e->cancel_pending;
+    h.chain_bytes = (uint32_t)sizeof(ChainDev);
+    h.live_upper = e->live_upper;
+    h.cfg_hash = snap_cfg_hash(e->cfg);
+    h.total_bytes = need;
+    size_t off = sizeof(SnapHeader);
+    memcpy(out + off, e->h_state.data(), e->cfg.capacity);                 // ActiveUser mirror
+    off += e->cfg.capacity;
+    memcpy(out + off, e->h_chains, (size_t)e->n_chains * sizeof(ChainDev)); // lengths + stored lobbies
+    off += (size_t)e->n_chains * sizeof(ChainDev);
+    const size_t cap_q = e->cfg.capacity;
+    for (uint32_t c = 0; c < e->n_chains; ++c) {                             // the queues, in order
+        const size_t len = e->h_chains[c].len;
+        if (!len) continue;
+        HIPCHK(e, hipMemcpyAsync(out + off, e->d_q_rating + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(out + off + len * 4u, e->d_q_cons + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(out + off + len * 8u, e->d_q_slot + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
+        off += len * 12u;
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    h.payload_hash = snap_hash(out + sizeof(SnapHeader), (size_t)need - sizeof(SnapHeader), 0xCBF29CE484222325ull);
+    memcpy(out, &h, sizeof(h));
+    *written = need;
+    return MM_OK;
+}
+
+extern "C" int mm_restore(mm_engine* e, const void* buf, uint64_t bytes)
+{
+    if (!e || !buf || bytes < sizeof(SnapHeader)) return MM_ERR_INVALID_ARG;
+    const unsigned char* in = (const unsigned char*)buf;
+    SnapHeader h;
+    memcpy(&h, in, sizeof(h));
+    if (h.magic != MM_SNAP_MAGIC || h.version != 1u || h.abi != MM_ABI_VERSION || h.header_bytes != sizeof(SnapHeader) ||
+        h.chain_bytes != sizeof(ChainDev) || h.total_bytes != bytes || h.capacity != e->cfg.capacity ||
+        h.n_groups != e->cfg.n_groups || h.n_modes != e->cfg.n_modes || h.n_chains != e->n_chains ||
+        h.cfg_hash != snap_cfg_hash(e->cfg))
+        return MM_ERR_INVALID_ARG;
+    if (h.payload_hash != snap_hash(in + sizeof(SnapHeader), (size_t)bytes - sizeof(SnapHeader), 0xCBF29CE484222325ull))
+        return MM_ERR_INVALID_ARG;
+    // structure check before anything is touched: the queue lengths have to add up
+    size_t off = sizeof(SnapHeader) + h.capacity;
+    const ChainDev* chains = (const ChainDev*)(in + off);
+    uint64_t need = off + (uint64_t)h.n_chains * sizeof(ChainDev);
+    for (uint32_t c = 0; c < h.n_chains; ++c) {
+        ChainDev cd;
+        memcpy(&cd, (const unsigned char*)chains + (size_t)c * sizeof(ChainDev), sizeof(cd));
+        if (cd.len > h.capacity) return MM_ERR_INVALID_ARG;
+        need += (uint64_t)cd.len * 12u;
+    }
+    if (need != bytes) return MM_ERR_INVALID_ARG;
+    int rc = mm_reset(e);
+    if (rc) return rc;
+    memcpy(e->h_state.data(), in + sizeof(SnapHeader), h.capacity);
+    HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state.data(), h.capacity, hipMemcpyHostToDevice, e->stream));
+    memcpy(e->h_chains, in + off, (size_t)h.n_chains * sizeof(ChainDev));
+    for (uint32_t c = 0; c < h.n_chains; ++c) {          // per-tick counters do not survive a restart
+        ChainDev& cd = e->h_chains[c];
+        cd.head_state = 0; cd.n_out = 0; cd.passes = 0; cd.err = 0; cd.purged = 0; cd.before = 0;
+        cd.pairs = 0; cd.scanned = 0;
+    }
+    HIPCHK(e, hipMemcpyAsync(e->d_chains, e->h_chains, (size_t)h.n_chains * sizeof(ChainDev), hipMemcpyHostToDevice, e->stream));
+    off += (size_t)h.n_chains * sizeof(ChainDev);
+    const size_t cap_q = e->cfg.capacity;
+    for (uint32_t c = 0; c < h.n_chains; ++c) {
+        const size_t len = e->h_chains[c].len;
+        if (!len) continue;
+        HIPCHK(e, hipMemcpyAsync(e->d_q_rating + c * cap_q, in + off, len * 4u, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_q_cons + c * cap_q, in + off + len * 4u, len * 4u, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_q_slot + c * cap_q, in + off + len * 8u, len * 4u, hipMemcpyHostToDevice, e->stream));
+        off += len * 12u;
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->next_slot = h.next_slot;
+    e->cancel_pending = h.cancel_pending;
+    e->live_upper = h.live_upper;
+    return MM_OK;
+}
+
 extern "C" int mm_last_hip_error(const mm_engine* e) { return e ? e->last_hip : 0; }

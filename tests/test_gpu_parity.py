@@ -267,6 +267,14 @@ def test_gpu_team_scan_horizon(gpu_cls, oracle_cls, monkeypatch, cap):
         assert_same_state(a, b, cfg)
 
 
+def test_gpu_restart_from_a_snapshot(gpu_cls, oracle_cls):
+    """mm_snapshot / mm_restore on the device: the engine is destroyed and rebuilt from its
+    snapshot three times (cancels pending across two of them); pools large enough for the pair
+    and team paths."""
+    from test_snapshot import restart_script
+    restart_script(gpu_cls, oracle_cls, n=120000, seed=5, capacity=1 << 19)
+
+
 def test_gpu_1v1_10m_pool(gpu_cls, oracle_cls):
     """BASELINE cfg-4 on one device: 10M players, 1v1 +-25 + region filter (chains of 1-3M players,
     hundreds of tiles per chain).  On a node the same chains spread over the ranks by rating group
