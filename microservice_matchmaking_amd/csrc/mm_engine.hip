@@ -1496,7 +1496,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
 
 // The team path (mm_team.inc).  *any is set when at least one chain was walked by it; the others
 // are left to k_walk.
-static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
+static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, bool* any)
 {
     const mm_config& cfg = e->cfg;
     const uint32_t G = cfg.n_groups;
@@ -1515,6 +1515,10 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
     P.pstride = e->pk_stride;
     P.chunk_stride = e->tk_chunk_stride;
     P.blk_stride = e->pk_stride / 64u;
+    P.purge = purge ? 1u : 0u;
+    P.state = e->d_state;
+    P.released = e->d_released;
+    P.n_released = e->d_counters;
     P.scan_cap = e->team_cap;
     P.debug = e->pair_debug ? 1u : 0u;
     P.M = M;
@@ -1571,8 +1575,9 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool* any)
     HIPCHK(e, hipGetLastError());
     if (e->pair_debug)
         for (uint32_t g = 0; g < G; ++g)
-            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | kt_f chunk 1 cycles/pass: stage %u scan(wave 0) %u scan(workgroup) %u tail %u\n", g, e->h_tchains[g].fast,
+            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | kt_f chunk 1 cycles/pass: stage %u scan(wave 0) %u scan(workgroup) %u tail %u\n", g, e->h_tchains[g].fast,
                     e->h_tchains[g].m, e->h_tchains[g].passes, e->h_tchains[g].n_out, e->h_tchains[g].qlen,
+                    e->h_tchains[g].dbg[6] & 1u, (e->h_tchains[g].dbg[6] >> 1) & 1u, (e->h_tchains[g].dbg[6] >> 2) & 1u, e->h_tchains[g].dbg[7],
                     e->h_tchains[g].dbg[0] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[1] / (e->h_tchains[g].passes + 1u),
                     e->h_tchains[g].dbg[2] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[3] / (e->h_tchains[g].passes + 1u));
     return MM_OK;
@@ -1603,10 +1608,10 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
         int prc = pair_walk(e, mode, M, purge);
         if (prc) return prc;
     }
-    // team modes: long chains of a tick without pending cancels take the team path
+    // team modes: long chains take the team path
     bool team_any = false;
-    if (!use_pair && !e->force_generic && !purge && e->live_upper >= TT_MIN) {
-        int trc = team_walk(e, mode, M, &team_any);
+    if (!use_pair && !e->force_generic && e->live_upper >= TT_MIN) {
+        int trc = team_walk(e, mode, M, purge, &team_any);
         if (trc) return trc;
     }
     WalkParams P;

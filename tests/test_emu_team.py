@@ -67,9 +67,11 @@ def test_team_narrow_window_scan_cap(oracle_cls):
                  lo=0, hi=1400, weights=W5) > 10
 
 
-def test_team_cancel_ticks_take_the_generic_kernel(oracle_cls):
-    """Ticks with pending cancels are walked by k_walk, the others by the team path; queues and
-    stored lobbies (also one whose first team a cancel emptied) carry over between the two."""
+def test_team_cancel_ticks(oracle_cls):
+    """Ticks with pending cancels on the team path: k_purge, then kt_init judges the head against
+    the stale lobby and filters it (the head sits out the first pass or is seated), and a stored
+    lobby whose lower teams a cancel emptied moves its anchor while it fills.  A 1v1 mode rides
+    along on the same engine (pair path)."""
     cfg = make_config([mode_team(3, 2, 300, (1, 1, 1)), mode_1v1(window=80, region_filter=True)], capacity=16384)
     rng = np.random.default_rng(21)
     with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
@@ -77,6 +79,56 @@ def test_team_cancel_ticks_take_the_generic_kernel(oracle_cls):
     rng = np.random.default_rng(22)
     with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
         random_scenario(rng, cfg, a, b, n_rounds=4, batch=2500, cancel_frac=0.0)
+
+
+@pytest.mark.parametrize("seed,mode,cancel_frac", [
+    (3, mode_team(1, 4, 30, (1,), region_filter=True), 0.2),       # four teams of one: the anchor moves often
+    (4, mode_team(5, 3, 5000, (1, 1, 2, 1)), 0.05),
+    (8, mode_team(2, 3, 5000, (2,), region_filter=True), 0.2),
+    (11, mode_team(2, 2, 150, (1, 1)), 0.05),
+])
+def test_team_cancel_ticks_lobby_shapes(oracle_cls, seed, mode, cancel_frac):
+    """Heavy cancelling on team modes with three and four teams: stale lobbies, heads that the
+    stale lobby takes or rejects, anchors that move down to an emptied team."""
+    cfg = make_config([mode], capacity=16384)
+    rng = np.random.default_rng(seed)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        random_scenario(rng, cfg, a, b, n_rounds=5, batch=1500, cancel_frac=cancel_frac)
+
+
+def test_team_anchor_moves_to_the_emptied_first_team(oracle_cls):
+    """Hand-built: the stored lobby is team 1: [A, C], team 2: [B]; A and C cancel.  The next
+    tick's head meets the stale lobby (anchor A: rejected, it sits out the pass), the filter
+    leaves team 2: [B] with B the anchor.  D fits B and is seated in the empty team 1, which makes
+    D the anchor: E (fits D, not B) is taken, F (fits B, not D) is not; G completes the lobby a
+    tick later."""
+    cfg = make_config([mode_team(2, 2, 100, (2,))], capacity=4096)
+    others = 1000 + 5 * np.arange(70)                    # one rating group, nobody near 500
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        def both(fn):
+            ra, rb = fn(a), fn(b)
+            return ra, rb
+        r1 = np.concatenate([[500, 510, 520], others]).astype(np.int32)
+        sa, sb = both(lambda e: e.enqueue(r1, cons_make(np.zeros(r1.size))))
+        assert np.array_equal(sa, sb)
+        ma, mb = both(lambda e: e.tick(0))
+        assert_same_tick(ma, mb, "tick 1")
+        assert_same_state(a, b, cfg, "tick 1")
+        slots, teams = a.lobby_state(0, 0)
+        assert slots.tolist() == [int(sa[0]), int(sa[2]), int(sa[1])] and teams.tolist() == [0, 0, 1]
+        both(lambda e: e.cancel(np.asarray([sa[0], sa[2]], np.uint32)))
+        r2 = np.asarray([600, 690, 450], np.int32)       # D, E, F
+        s2, _ = both(lambda e: e.enqueue(r2, cons_make(np.zeros(3))))
+        ma, mb = both(lambda e: e.tick(0))
+        assert_same_tick(ma, mb, "tick 2")
+        assert_same_state(a, b, cfg, "tick 2")
+        slots, teams = a.lobby_state(0, 0)
+        assert slots.tolist() == [int(s2[0]), int(sa[1]), int(s2[1])] and teams.tolist() == [0, 1, 1]
+        s3, _ = both(lambda e: e.enqueue(np.asarray([650], np.int32), cons_make(np.zeros(1))))
+        ma, mb = both(lambda e: e.tick(0))
+        assert_same_tick(ma, mb, "tick 3")
+        assert len(ma) >= 1 and ma.slots[0].tolist() == [int(s2[0]), int(s3[0]), int(sa[1]), int(s2[1])]
+        assert_same_state(a, b, cfg, "tick 3")
 
 
 def test_team_short_chains_stay_with_k_walk(oracle_cls):
