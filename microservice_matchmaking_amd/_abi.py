@@ -94,6 +94,42 @@ PRODUCT_ONLY_FUNCTIONS = ["abi_version", "strerror", "config_default", "enqueue_
                           "last_hip_error"]
 
 
+class MMCodecCfg(C.Structure):
+    """include/mm_codec.h mm_codec_cfg."""
+    _fields_ = [("n_modes", C.c_uint32), ("mode_name", C.c_char_p * 16),
+                ("region_key", C.c_char_p), ("party_key", C.c_char_p), ("role_key", C.c_char_p)]
+
+
+DEC_OK, DEC_BAD_JSON, DEC_NO_MODE, DEC_BAD_FIELD, DEC_RATING_INEXACT, DEC_RATING_NOT_NUMBER = range(6)
+
+
+def decode_players(lib, cfg, mode_names, messages, region_key=None, party_key=None, role_key=None):
+    """mm_decode_players over a list of `bytes` payloads -> dict of numpy columns."""
+    cc = MMCodecCfg()
+    cc.n_modes = len(mode_names)
+    for k, name in enumerate(mode_names):
+        cc.mode_name[k] = name.encode()
+    cc.region_key = region_key.encode() if region_key else None
+    cc.party_key = party_key.encode() if party_key else None
+    cc.role_key = role_key.encode() if role_key else None
+    n = len(messages)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    if n:
+        off[1:] = np.cumsum([len(m) for m in messages])
+    buf = b"".join(messages)
+    out = {"rating": np.zeros(n, np.int32), "cons": np.zeros(n, np.uint32), "group": np.zeros(n, np.uint8),
+           "status": np.zeros(n, np.uint8), "id_off": np.zeros(n, np.uint32), "id_len": np.zeros(n, np.uint32)}
+    fn = lib.mm_decode_players
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(MMConfig), C.POINTER(MMCodecCfg), C.c_char_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+    rc = fn(C.byref(cfg), C.byref(cc), buf, _ptr(off), n, *[_ptr(out[k]) for k in
+                                                            ("rating", "cons", "group", "status", "id_off", "id_len")])
+    if rc != 0:
+        raise MMError(rc, "mm_decode_players")
+    out["ids"] = [messages[i][int(out["id_off"][i]):int(out["id_off"][i]) + int(out["id_len"][i])] for i in range(n)]
+    return out
+
+
 def bind(lib, prefix):
     """Set argtypes/restype for the common ABI under `prefix` ('mm_' or 'mo_')."""
     u32p = C.POINTER(C.c_uint32)

@@ -1917,3 +1917,5 @@ extern "C" int mm_restore(mm_engine* e, const void* buf, uint64_t bytes)
 }
 
 extern "C" int mm_last_hip_error(const mm_engine* e) { return e ? e->last_hip : 0; }
+
+#include "mm_codec.inc"

@@ -12,13 +12,15 @@ from microservice_matchmaking_amd import MMError, make_config, mode_1v1
 from microservice_matchmaking_amd._abi import MMConfig, MMEnqueueStats, MMModeConfig, MMStats
 from microservice_matchmaking_amd.engine import LIB_PATH, load_library
 
-HEADER = os.path.join(ROOT, "include", "mm_engine.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("mm_engine.h", "mm_codec.h")]
 
 
 def declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mm_[a-z_]+)\s*\(", src)))
+    names = set()
+    for h in HEADERS:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(mm_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 @pytest.fixture(scope="module")
@@ -40,7 +42,7 @@ def test_oracle_exports_the_mirrored_abi(oracle_cls):
     olib = load()
     for n in declared_functions():
         if n in ("mm_abi_version", "mm_strerror", "mm_config_default", "mm_enqueue_device",
-                 "mm_last_hip_error", "mm_snapshot_size", "mm_snapshot", "mm_restore"):
+                 "mm_last_hip_error", "mm_snapshot_size", "mm_snapshot", "mm_restore", "mm_decode_players"):
             continue
         assert hasattr(olib, "mo_" + n[3:]), n
 

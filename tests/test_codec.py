@@ -1,0 +1,176 @@
+"""include/mm_codec.h — the enqueue-side codec.  Host code of
+libmm_engine.so, so these tests need no GPU.  The checker is Python's json module (strict
+UTF-8) plus oracle/literal_ref.find_rating_group_by_rating, the line-by-line restatement of
+lib/generic/worker.ex:46-53 (Erlang term order for non-numbers included)."""
+import json
+import time
+
+import numpy as np
+import pytest
+
+from microservice_matchmaking_amd._abi import (DEC_BAD_FIELD, DEC_BAD_JSON, DEC_NO_MODE, DEC_OK,
+                                               DEC_RATING_INEXACT, DEC_RATING_NOT_NUMBER, cons_make, decode_players)
+from microservice_matchmaking_amd.config import make_config, mode_1v1, mode_team
+from microservice_matchmaking_amd.engine import load_library
+from oracle.literal_ref import RATING_GROUPS, find_rating_group_by_rating
+
+MODES = ["duel", "5v5 ranked"]
+CFG = make_config([mode_1v1(window=25, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1024)
+GROUP_INDEX = {g[2]: i for i, g in enumerate(RATING_GROUPS)}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return load_library()
+
+
+def expect(msg: bytes):
+    """(status, rating, cons, group, id) the reference's two decode sites imply for one payload."""
+    try:
+        d = json.loads(msg.decode("utf-8"), parse_constant=lambda s: (_ for _ in ()).throw(ValueError(s)))
+    except (ValueError, UnicodeDecodeError, RecursionError):
+        return (DEC_BAD_JSON, 0, 0, 0, None)
+    if not isinstance(d, dict):
+        return (DEC_BAD_JSON, 0, 0, 0, None)
+    gm = d.get("game-mode")
+    if not isinstance(gm, str) or gm not in MODES:
+        return (DEC_NO_MODE, 0, 0, 0, None)
+    ext = []
+    for k in ("region", "party", "role"):
+        v = d.get(k, 0) if k in d else 0
+        if k in d and (isinstance(v, bool) or not isinstance(v, int)):
+            return (DEC_BAD_FIELD, 0, 0, 0, None)
+        ext.append(v)
+    if not (0 <= ext[0] <= 255 and 0 <= ext[1] <= 15 and 0 <= ext[2] <= 15):
+        return (DEC_BAD_FIELD, 0, 0, 0, None)
+    cons = int(cons_make(MODES.index(gm), ext[0], ext[1], ext[2]))
+    r = d.get("rating")
+    group = GROUP_INDEX[find_rating_group_by_rating(r)[2]]
+    if isinstance(r, bool) or not isinstance(r, (int, float)):
+        return (DEC_RATING_NOT_NUMBER, 0, cons, group, d.get("id"))
+    exact = float(r).is_integer() and -2 ** 31 <= r <= 2 ** 31 - 1 if not isinstance(r, int) else -2 ** 31 <= r <= 2 ** 31 - 1
+    if exact:
+        return (DEC_OK, int(r), cons, group, d.get("id"))
+    fl = int(np.floor(float(r))) if abs(float(r)) < 2.0 ** 62 else (2 ** 62 if r > 0 else -2 ** 62)
+    return (DEC_RATING_INEXACT, int(min(max(fl, -2 ** 31), 2 ** 31 - 1)), cons, group, d.get("id"))
+
+
+def check(lib, msgs):
+    out = decode_players(lib, CFG, MODES, msgs, region_key="region", party_key="party", role_key="role")
+    for i, m in enumerate(msgs):
+        st, rating, cons, group, pid = expect(m)
+        got = (int(out["status"][i]), int(out["rating"][i]), int(out["cons"][i]), int(out["group"][i]))
+        assert got == (st, rating, cons, group), (m, got, (st, rating, cons, group))
+        if st in (DEC_OK, DEC_RATING_INEXACT, DEC_RATING_NOT_NUMBER):
+            if isinstance(pid, str):
+                assert json.loads(b'"' + out["ids"][i] + b'"') == pid, m
+            elif isinstance(pid, (int, float)) and not isinstance(pid, bool):
+                assert json.loads(out["ids"][i]) == pid, m
+            else:
+                assert out["ids"][i] == b"", m
+    return out
+
+
+def test_payloads_as_the_middleware_writes_them(lib):
+    rng = np.random.default_rng(1)
+    msgs = []
+    for k in range(3000):
+        d = {"id": "user-%d-é中\U0001f600" % k, "rating": int(rng.integers(0, 5001)),
+             "game-mode": MODES[int(rng.integers(0, 2))], "response-queue": "amq.gen-%d" % k,
+             "event-name": "find-game", "detail": {"rating": "decoy", "nested": [1, 2.5, None, {"game-mode": 1}]},
+             "region": int(rng.integers(0, 8)), "role": int(rng.integers(0, 5))}
+        items = list(d.items())
+        rng.shuffle(items)
+        seps = [(",", ":"), (", ", ": "), (" ,\n", " :\t")][k % 3]
+        msgs.append(json.dumps(dict(items), separators=seps, ensure_ascii=bool(k & 1)).encode("utf-8"))
+    out = check(lib, msgs)
+    assert (out["status"] == DEC_OK).all()
+
+
+def test_ratings_the_way_erlang_compares_them(lib):
+    base = '{"game-mode":"duel","id":7,"rating":%s}'
+    ratings = ["0", "-0", "1499", "1499.5", "1500", "1500.0", "1.5e3", "15E2", "2999.999", "3000", "5000", "5000.0001",
+               "5001", "-1", "-0.5", "1e400", "-1e400", "123456789012345678901234567890", "2147483647", "2147483648",
+               "-2147483648", "-2147483649", "4.0e3", "0.0", "1E-5", "null", "true", "false", '"1500"', "[1500]",
+               '{"a":1}']
+    msgs = [(base % r).encode() for r in ratings] + [b'{"game-mode":"duel"}', b'{"rating":1,"game-mode":"5v5 ranked","rating":4200}']
+    out = check(lib, msgs)
+    by = dict(zip(ratings, out["status"][:len(ratings)].tolist()))
+    assert by["1500.0"] == DEC_OK and by["1499.5"] == DEC_RATING_INEXACT and by["null"] == DEC_RATING_NOT_NUMBER
+    assert out["group"][ratings.index("1499.5")] == 4          # the gap between bronze and silver: default group
+    assert out["rating"][-1] == 4200                            # duplicate key: the last one wins
+
+
+def test_modes_fields_and_keys_with_escapes(lib):
+    msgs = [r'{"game-mode":"5v5 ranked","rating":2000,"role":4,"party":3,"region":255,"id":"a\"b\\cé"}'.encode("utf-8"),
+            b'{"game-mode":"duel","rating":10}',
+            b'{"game-mode":"duel ","rating":10}', b'{"game-mode":7,"rating":10}', b'{"rating":10}',
+            b'{"game-mode":"duel","rating":10,"role":16}', b'{"game-mode":"duel","rating":10,"region":-1}',
+            b'{"game-mode":"duel","rating":10,"party":1.0}', b'{"game-mode":"duel","rating":10,"role":"2"}',
+            b'  {"game-mode" : "duel" , "rating" : 10 }\r\n', b'{"game-mode":"du\\u0065l","rating":10,"id":12.5}']
+    out = check(lib, msgs)
+    assert out["status"].tolist() == [DEC_OK, DEC_OK, DEC_NO_MODE, DEC_NO_MODE, DEC_NO_MODE, DEC_BAD_FIELD, DEC_BAD_FIELD,
+                                      DEC_BAD_FIELD, DEC_BAD_FIELD, DEC_OK, DEC_OK]
+
+
+def test_what_poison_decode_would_raise_on(lib):
+    good = b'{"game-mode":"duel","rating":10,"id":"x"}'
+    bad = [good[:-1], good + b"x", good + good, b"", b"   ", b"[1]", b"10", b'"str"', b"null",
+           b"{'game-mode':'duel','rating':10}", b'{"game-mode":"duel","rating":010}', b'{"game-mode":"duel","rating":+1}',
+           b'{"game-mode":"duel","rating":.5}', b'{"game-mode":"duel","rating":1.}', b'{"game-mode":"duel","rating":1e}',
+           b'{"game-mode":"duel","rating":NaN}', b'{"game-mode":"duel","rating":Infinity}', b'{"game-mode":"duel","rating":-}',
+           b'{"game-mode":"duel","rating":10,}', b'{"game-mode":"duel" "rating":10}', b'{"game-mode":"duel","rating"10}',
+           b'{"game-mode":"du\nel","rating":10}', b'{"game-mode":"du\\xel","rating":10}', b'{"game-mode":"duel","x":"\\u12g4"}',
+           b'{"game-mode":"duel","x":"\xff"}', b'{"game-mode":"duel","x":"\xc0\xaf"}', b'{"game-mode":"duel","x":"\xed\xa0\x80"}',
+           b'{"game-mode":"duel","x":"\xf4\x90\x80\x80"}', b'{"game-mode":"duel","x":"\xe4\xb8"}', b'{"game-mode":"duel","x":tru}',
+           b'{"game-mode":"duel","x":[1,2}', b'{"game-mode":"duel","x":{"a":}}', b'{"game-mode":"duel",10:1}',
+           b"{" * 400 + b"}" * 400]
+    out = check(lib, bad)
+    assert (out["status"] == DEC_BAD_JSON).all()
+    # nesting: 200 levels are read like any other value; the reader gives up beyond 512 (its one
+    # deliberate difference from a recursive decoder, which would run out of stack much later)
+    deep = lambda k: b'{"game-mode":"duel","rating":10,"detail":' + b"[" * k + b"]" * k + b"}"
+    out = check(lib, [deep(200)])
+    assert out["status"].tolist() == [DEC_OK]
+    out = decode_players(lib, CFG, MODES, [deep(600)])
+    assert out["status"].tolist() == [DEC_BAD_JSON]
+
+
+def test_mutated_payloads_agree_with_the_checker(lib):
+    """Byte-level mutations of valid payloads: accepted or refused exactly like the checker, and
+    the same columns when accepted."""
+    rng = np.random.default_rng(7)
+    seeds = [b'{"id":"p-1","rating":1500,"game-mode":"duel","region":3}',
+             b'{"game-mode":"5v5 ranked","rating":2750.5,"role":2,"detail":{"a":[1,2,{"b":null}],"s":"x\\ny\\u00e9"},"id":99}',
+             '{"rating":-12,"game-mode":"duel","id":"ü中","party":1}'.encode("utf-8")]
+    alphabet = b'{}[]":,.-+eE0123456789tfnul\\ \n"ag'
+    msgs = []
+    for k in range(6000):
+        m = bytearray(seeds[k % len(seeds)])
+        for _ in range(int(rng.integers(1, 4))):
+            op, pos = int(rng.integers(0, 3)), int(rng.integers(0, len(m)))
+            if op == 0:
+                m[pos] = alphabet[int(rng.integers(0, len(alphabet)))]
+            elif op == 1:
+                del m[pos]
+            else:
+                m.insert(pos, alphabet[int(rng.integers(0, len(alphabet)))])
+            if not m:
+                m = bytearray(b" ")
+        msgs.append(bytes(m))
+    out = check(lib, msgs)
+    assert 0 < int((out["status"] == DEC_BAD_JSON).sum()) < len(msgs)
+
+
+def test_decode_rate_is_far_above_the_stream(lib):
+    """BASELINE cfg-5 streams 100k players/s; one host core decodes well over a million."""
+    msgs = [json.dumps({"id": "user-%07d" % k, "rating": 1000 + k % 3000, "game-mode": MODES[k & 1],
+                        "response-queue": "amq.gen-%d" % k, "event-name": "find-game", "region": k % 8,
+                        "role": k % 5}).encode() for k in range(200000)]
+    t0 = time.perf_counter()
+    out = decode_players(lib, CFG, MODES, msgs, region_key="region", party_key="party", role_key="role")
+    dt = time.perf_counter() - t0                     # includes the Python-side join of the batch
+    assert (out["status"] == DEC_OK).all()
+    rate = len(msgs) / dt
+    print("decode: %.2f M messages/s, %.0f MB/s (incl. Python batch assembly)" % (rate / 1e6, sum(map(len, msgs)) / dt / 1e6))
+    assert rate > 300000
