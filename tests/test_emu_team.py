@@ -131,6 +131,25 @@ def test_team_anchor_moves_to_the_emptied_first_team(oracle_cls):
         assert_same_state(a, b, cfg, "tick 3")
 
 
+def test_team_extreme_ratings_fall_back(oracle_cls):
+    """A chain whose rating span does not fit the packed key is walked by the generic kernel,
+    its neighbours by the team path, in the same tick."""
+    cfg = make_config([mode_team(2, 2, 60, (1, 1))], capacity=8192)
+    rng = np.random.default_rng(5)
+    n = 1200
+    rating = rng.integers(3000, 3400, size=n).astype(np.int32)
+    rating[::200] = np.asarray([2**31 - 1, -2**31, 2**31 - 5, -2**31 + 7, 2**30, -2**30], np.int32)
+    grp = np.full(n, 4, np.uint8)             # host routed them all to one group ...
+    rating2 = rng.integers(1500, 2000, size=600).astype(np.int32)      # ... and these go where they belong
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        cons = cons_make(0, 0, 0, rng.integers(0, 2, size=n))
+        assert np.array_equal(a.enqueue(rating, cons, grp), b.enqueue(rating, cons, grp))
+        cons2 = cons_make(0, 0, 0, rng.integers(0, 2, size=600))
+        assert np.array_equal(a.enqueue(rating2, cons2), b.enqueue(rating2, cons2))
+        assert_same_tick(a.tick(0), b.tick(0), "extreme")
+        assert_same_state(a, b, cfg)
+
+
 def test_team_short_chains_stay_with_k_walk(oracle_cls):
     """Product geometry (TT_MIN=4096): one long chain takes the team path, the short ones of the
     same tick are walked by k_walk."""
