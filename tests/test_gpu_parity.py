@@ -292,6 +292,21 @@ def test_gpu_1v1_10m_pool(gpu_cls, oracle_cls):
         check_properties(cfg, 0, rating, cons, ma, n)
 
 
+def test_gpu_5v5_10m_pool(gpu_cls, oracle_cls):
+    """Ten times BASELINE cfg-3 on one device: chains of 1-3M players (thousands of chunks per
+    chain for the team path's kernels)."""
+    n = 10_000_000
+    cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 24)
+    rating, cons = make_pool(n, seed=6, role_weights=ROLE_WEIGHTS_5V5)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        a.enqueue(rating, cons)
+        b.enqueue(rating, cons)
+        ma, mb = a.tick(0), b.tick(0)
+        assert_same_tick(ma, mb, "5v5 10M", SCORE_TOL)
+        assert_same_state(a, b, cfg)
+        check_properties(cfg, 0, rating, cons, ma, n)
+
+
 def test_gpu_randomised_stress_short(gpu_cls, monkeypatch):
     """Ten seconds of tools/gpu_stress.py: seeded random pools / predicates / multi-tick scripts
     with arrivals and cancels, every tick bit-exact against the oracle."""
