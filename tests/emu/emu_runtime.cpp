@@ -2,6 +2,7 @@
  * TEST INFRASTRUCTURE ONLY (see the header). */
 #include "hip/hip_runtime.h"
 
+#include <setjmp.h>
 #include <time.h>
 #include <ucontext.h>
 
@@ -15,7 +16,9 @@ enum State { RUNNABLE, AT_BARRIER, AT_WAVEOP, DONE };
 enum WaveOp { OP_NONE, OP_BALLOT, OP_SHFL };
 
 struct Fiber {
-    ucontext_t ctx;
+    ucontext_t ctx;           /* first entry only; afterwards _setjmp/_longjmp (no signal-mask syscalls) */
+    jmp_buf jb;
+    bool started = false;
     char* stack = nullptr;
     State state = RUNNABLE;
     WaveOp op = OP_NONE;
@@ -26,7 +29,9 @@ struct Fiber {
 
 const size_t kStack = 256 * 1024;
 std::vector<Fiber> g_fibers;
+std::vector<char*> g_stacks;  /* pooled: a block of 1024 threads would otherwise map 256 MB per launch */
 ucontext_t g_sched;
+jmp_buf g_sched_jb;
 int g_cur = -1;
 const std::function<void()>* g_body = nullptr;
 
@@ -34,10 +39,24 @@ void fiber_main()
 {
     (*g_body)();
     g_fibers[g_cur].state = DONE;
-    swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+    _longjmp(g_sched_jb, 1);
 }
 
-void yield_to_sched() { swapcontext(&g_fibers[g_cur].ctx, &g_sched); }
+void yield_to_sched()
+{
+    if (_setjmp(g_fibers[g_cur].jb) == 0) _longjmp(g_sched_jb, 1);
+}
+
+/* run fiber t until it yields or finishes */
+void resume(unsigned t)
+{
+    Fiber& f = g_fibers[t];
+    if (_setjmp(g_sched_jb) != 0) return;
+    if (!f.started) {
+        f.started = true;
+        swapcontext(&g_sched, &f.ctx);   /* never returns here: fibers leave through g_sched_jb */
+    } else _longjmp(f.jb, 1);
+}
 
 [[noreturn]] void die(const char* msg)
 {
@@ -80,9 +99,10 @@ int emu_shfl_i32(int v, int src_lane)
 static void run_block(unsigned nthreads)
 {
     g_fibers.assign(nthreads, Fiber());
+    while (g_stacks.size() < nthreads) g_stacks.push_back((char*)malloc(kStack));
     for (unsigned t = 0; t < nthreads; ++t) {
         Fiber& f = g_fibers[t];
-        f.stack = (char*)malloc(kStack);
+        f.stack = g_stacks[t];
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = kStack;
@@ -96,7 +116,7 @@ static void run_block(unsigned nthreads)
             if (g_fibers[t].state != RUNNABLE) continue;
             g_cur = (int)t;
             threadIdx.x = t;
-            swapcontext(&g_sched, &g_fibers[t].ctx);
+            resume(t);
             progress = true;
             if (g_fibers[t].state == DONE) ++done;
         }
@@ -148,7 +168,6 @@ static void run_block(unsigned nthreads)
         }
         if (!progress && done < nthreads) die("deadlock: divergent collective or barrier");
     }
-    for (unsigned t = 0; t < nthreads; ++t) free(g_fibers[t].stack);
     g_fibers.clear();
 }
 
