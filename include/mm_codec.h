@@ -58,6 +58,32 @@ int mm_decode_players(const mm_config* cfg, const mm_codec_cfg* cc, const char* 
                       int32_t* rating, uint32_t* cons, uint8_t* group, uint8_t* status,
                       uint32_t* id_off, uint32_t* id_len);
 
+/* the lobby the search stage publishes,
+ *   Poison.encode!(%{"teams" => updated_grouped_players, "game-mode" => game_mode})
+ *                                                        lib/search/worker.ex:315-318
+ * read back by the lobby worker with Poison.decode! (lib/game-lobby/worker.ex:119-127:
+ * data["teams"], data["game-mode"], required slots = players over all teams, :37-39).
+ * A player inside it is its delivery payload as decoded, minus the "game-mode" member
+ * (Map.pop, worker.ex:294); the teams are "team 1", "team 2", ... (docs/MATCH_CHECK.md
+ * section 1).
+ *
+ * Input: the L = teams * team_size payloads of one lobby in mm_matches order (team major,
+ * seating order inside the team), as they were delivered.  Output: one JSON object.  Members
+ * are written in ascending key order on the three levels this function builds (the lobby, the
+ * teams map, each player; a duplicate key keeps its last value, as a map would); member names
+ * are written with the minimal escapes; every player VALUE — numbers, strings, nested
+ * objects — is copied byte for byte from the payload, so nothing is re-formatted.
+ *
+ * Equivalence bar: the output decodes to exactly the map the reference builds (checked with
+ * Python's json against a dict-level restatement, tests/test_codec.py).  Byte identity with
+ * Poison's own output is NOT claimed: the key order of Poison's map encoder and its float
+ * formatting cannot be pinned in this container, and the consumer decodes anyway.
+ *
+ * *written = bytes needed; MM_ERR_RANGE if cap is smaller (nothing useful in out then);
+ * MM_ERR_INVALID_ARG for a payload that is not a JSON object or bad arguments. */
+int mm_encode_lobby(const char* game_mode, uint32_t teams, uint32_t team_size, const char* const* payload,
+                    const uint32_t* payload_len, char* out, uint64_t cap, uint64_t* written);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,26 @@ def decode_players(lib, cfg, mode_names, messages, region_key=None, party_key=No
     return out
 
 
+def encode_lobby(lib, game_mode, teams, team_size, payloads):
+    """mm_encode_lobby: the L payloads of one lobby (team major) -> the published JSON (bytes)."""
+    n = len(payloads)
+    arr = (C.c_char_p * n)(*payloads)
+    lens = np.asarray([len(p) for p in payloads], dtype=np.uint32)
+    fn = lib.mm_encode_lobby
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_uint64,
+                   C.POINTER(C.c_uint64)]
+    w = C.c_uint64()
+    rc = fn(game_mode.encode("utf-8"), teams, team_size, arr, _ptr(lens), None, 0, C.byref(w))
+    if rc not in (0, -8):                     # MM_ERR_RANGE: the size query
+        raise MMError(rc, "mm_encode_lobby")
+    buf = np.empty(int(w.value), dtype=np.uint8)
+    rc = fn(game_mode.encode("utf-8"), teams, team_size, arr, _ptr(lens), _ptr(buf), C.c_uint64(buf.size), C.byref(w))
+    if rc != 0:
+        raise MMError(rc, "mm_encode_lobby")
+    return buf.tobytes()
+
+
 def bind(lib, prefix):
     """Set argtypes/restype for the common ABI under `prefix` ('mm_' or 'mo_')."""
     u32p = C.POINTER(C.c_uint32)

@@ -40,6 +40,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 

@@ -8,8 +8,10 @@ import time
 import numpy as np
 import pytest
 
+from microservice_matchmaking_amd import MMError
 from microservice_matchmaking_amd._abi import (DEC_BAD_FIELD, DEC_BAD_JSON, DEC_NO_MODE, DEC_OK,
-                                               DEC_RATING_INEXACT, DEC_RATING_NOT_NUMBER, cons_make, decode_players)
+                                               DEC_RATING_INEXACT, DEC_RATING_NOT_NUMBER, cons_make, decode_players,
+                                               encode_lobby)
 from microservice_matchmaking_amd.config import make_config, mode_1v1, mode_team
 from microservice_matchmaking_amd.engine import load_library
 from oracle.literal_ref import RATING_GROUPS, find_rating_group_by_rating
@@ -174,3 +176,61 @@ def test_decode_rate_is_far_above_the_stream(lib):
     rate = len(msgs) / dt
     print("decode: %.2f M messages/s, %.0f MB/s (incl. Python batch assembly)" % (rate / 1e6, sum(map(len, msgs)) / dt / 1e6))
     assert rate > 300000
+
+
+# ---- mm_encode_lobby ----------------------------------------
+
+def lobby_as_the_reference_builds_it(game_mode, teams, team_size, payloads):
+    """search/worker.ex:292-318 at the level of maps: every player is its decoded payload
+    minus "game-mode"; teams "team 1".. in mm_matches order."""
+    players = []
+    for p in payloads:
+        d = json.loads(p.decode("utf-8"))
+        d.pop("game-mode", None)
+        players.append(d)
+    return {"teams": {"team %d" % (t + 1): players[t * team_size:(t + 1) * team_size] for t in range(teams)},
+            "game-mode": game_mode}
+
+
+def test_lobby_decodes_to_the_map_the_reference_publishes(lib):
+    rng = np.random.default_rng(3)
+    for teams, team_size in ((2, 1), (2, 5), (3, 2), (4, 4)):
+        payloads = []
+        for k in range(teams * team_size):
+            d = {"id": "p-%d-é\"\\\n中" % k, "rating": int(rng.integers(0, 5001)), "game-mode": "5v5 ranked",
+                 "response-queue": "amq.gen-%d" % k, "event-name": "find-game",
+                 "detail": {"z": [1, 2.50, None, True], "a": {"game-mode": "kept: nested"}}, "role": k % 5,
+                 "weird \u00e9 key\t": 1e-7, "big": 123456789012345678901234567890}
+            items = list(d.items())
+            rng.shuffle(items)
+            payloads.append(json.dumps(dict(items), ensure_ascii=bool(k & 1), separators=[(",", ":"), (" , ", " : ")][k & 1]).encode("utf-8"))
+        out = encode_lobby(lib, "5v5 ranked", teams, team_size, payloads)
+        assert json.loads(out.decode("utf-8")) == lobby_as_the_reference_builds_it("5v5 ranked", teams, team_size, payloads)
+        # the three levels this function builds: ascending keys, no insignificant whitespace
+        assert out.startswith(b'{"game-mode":"5v5 ranked","teams":{"team 1":[{')
+        top = json.loads(out.decode("utf-8"), object_pairs_hook=list)
+        assert [k for k, _ in top] == ["game-mode", "teams"]
+        assert [k for k, _ in top[1][1]] == ["team %d" % (t + 1) for t in range(teams)]
+        for _, players in top[1][1]:
+            for pl in players:
+                keys = [k.encode("utf-8") for k, _ in pl]
+                assert keys == sorted(keys) and b"game-mode" not in keys
+        # required slots as the lobby worker counts them (game-lobby/worker.ex:37-39)
+        assert sum(len(v) for v in json.loads(out.decode("utf-8"))["teams"].values()) == teams * team_size
+
+
+def test_lobby_values_are_copied_byte_for_byte(lib):
+    a = b'{"rating":1.50e3,"id":"\\u0041\\/b","game-mode":"duel","n":{"y" : 1 ,"x":[ 1,2 ]},"rating":7}'
+    b = b' { "id" : 2 , "g\\u0061me-mode" : "duel" , "k\\"ey" : -0.0 } '
+    out = encode_lobby(lib, 'du"el', 2, 1, [a, b])
+    assert out == (b'{"game-mode":"du\\"el","teams":{"team 1":[{"id":"\\u0041\\/b","n":{"y" : 1 ,"x":[ 1,2 ]},"rating":7}],'
+                   b'"team 2":[{"id":2,"k\\"ey":-0.0}]}}')
+
+
+def test_lobby_refuses_what_is_not_a_player_object(lib):
+    good = b'{"id":1,"game-mode":"duel"}'
+    for bad in (b"[1]", b'{"id":1', b'{"id":1}x', b"", b'{"id":01}'):
+        with pytest.raises(MMError):
+            encode_lobby(lib, "duel", 2, 1, [good, bad])
+    with pytest.raises(MMError):
+        encode_lobby(lib, "duel", 5, 4, [good] * 20)           # more than MM_MAX_LOBBY seats
