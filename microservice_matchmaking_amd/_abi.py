@@ -8,6 +8,7 @@ identical calls, which is what makes the parity tests read like one test run twi
 from __future__ import annotations
 
 import ctypes as C
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -122,10 +123,13 @@ def decode_players(lib, cfg, mode_names, messages, region_key=None, party_key=No
     fn = lib.mm_decode_players
     fn.restype = C.c_int
     fn.argtypes = [C.POINTER(MMConfig), C.POINTER(MMCodecCfg), C.c_char_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+    t0 = time.perf_counter()
     rc = fn(C.byref(cfg), C.byref(cc), buf, _ptr(off), n, *[_ptr(out[k]) for k in
                                                             ("rating", "cons", "group", "status", "id_off", "id_len")])
+    seconds = time.perf_counter() - t0
     if rc != 0:
         raise MMError(rc, "mm_decode_players")
+    out["seconds"] = seconds                  # the C call alone (batch assembly above is Python's)
     out["ids"] = [messages[i][int(out["id_off"][i]):int(out["id_off"][i]) + int(out["id_len"][i])] for i in range(n)]
     return out
 
