@@ -2,7 +2,11 @@
 """Randomised differential stress on a real GPU: HIP engine vs oracle over many seeded
 scenarios (pool sizes that hit the LDS-resident walk, the tiled rounds and the hand-over
 between them; windows from 0 to wider than the rating span; 1..64 regions; multi-tick with
-arrivals and cancels).  Usage: python tools/gpu_stress.py [seconds] [seed]"""
+arrivals and cancels).  Usage: python tools/gpu_stress.py [seconds] [seed] [team]
+
+MM_STRESS_ENGINE=emu_small runs the same scenarios without a GPU on the fiber-shim build of the
+kernel source with the tiny tile geometry (tests/emu/), pool sizes divided by 16 so that they
+land on the same paths (LDS-resident walk / tiled rounds / hand-over; team path / k_walk)."""
 import os
 import sys
 import time
@@ -16,6 +20,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import assert_same_state, assert_same_tick  # noqa: E402
 from microservice_matchmaking_amd import Engine, cons_make, make_config, mode_1v1, mode_team  # noqa: E402
 from oracle.oracle import OracleEngine  # noqa: E402
+
+SCALE = 1
+if os.environ.get("MM_STRESS_ENGINE", "gpu") == "emu_small":
+    from emu_engine import EmuEngineSmall as Engine  # noqa: E402,F811
+    SCALE = 16
+
+
+def scaled(n):
+    return int(n) // SCALE if n >= 100 else int(n)
 
 
 def random_team_mode(rng):
@@ -52,8 +65,8 @@ def team_main(budget, seed0):
             hi = lo + 600
         w = rng.random(nr) + 0.05
         w /= w.sum()
-        sizes = [int(rng.choice([3000, 20000, 60000, 120000]))] + \
-                [int(rng.choice([0, 100, 5000, 30000])) for _ in range(int(rng.integers(0, 4)))]
+        sizes = [scaled(rng.choice([3000, 20000, 60000, 120000]))] + \
+                [scaled(rng.choice([0, 100, 5000, 30000])) for _ in range(int(rng.integers(0, 4)))]
         tag = "team seed %d mode=%s ratings=[%d,%d] sizes=%s" % (seed, modes[0], lo, hi, sizes)
         with Engine(cfg) as a, OracleEngine(cfg) as b:
             live = np.zeros(0, np.uint32)
@@ -100,8 +113,8 @@ def main():
         hi = int(rng.choice([1499, 2600, 5000, 5000]))
         if hi <= lo:
             hi = lo + 600
-        sizes = [int(rng.choice([50, 3000, 20000, 70000, 150000, 260000]))] + \
-                [int(rng.choice([0, 100, 5000, 40000])) for _ in range(int(rng.integers(0, 4)))]
+        sizes = [scaled(rng.choice([50, 3000, 20000, 70000, 150000, 260000]))] + \
+                [scaled(rng.choice([0, 100, 5000, 40000])) for _ in range(int(rng.integers(0, 4)))]
         tag = "seed %d w=%d regions=%d party=%d modes=%d ratings=[%d,%d] sizes=%s" % (
             seed, window, regions, party, len(modes), lo, hi, sizes)
         with Engine(cfg) as a, OracleEngine(cfg) as b:
