@@ -67,7 +67,7 @@ def test_default_config_and_rating_groups(beam):
 
 def scenario(beam, n=6000, seed=5):
     """enqueue -> tick -> cancel -> tick for both modes, every reply checked against the oracle."""
-    cfg = make_config(MODES, capacity=1 << 14)
+    cfg = make_config(MODES, capacity=1 << max(14, int(n).bit_length() + 1))
     ok, eng = beam.call("create", cfg_bin(cfg))
     assert ok == "ok" and isinstance(eng, Resource)
     rating, cons = make_pool(n, seed=seed, role_weights=ROLE_WEIGHTS_5V5)
