@@ -38,7 +38,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # MI355X_MICROARCH.md: measured copy ceiling (SURVEY.md §8(d) asks for both)
 BYTES_PER_PAIR = 8
+
+
+def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passes_max, traffic):
+    """The `roofline` object of the bench line (pure arithmetic; tests/test_bench_line.py).
+    SURVEY.md §8(d): achieved = algorithmic bytes / walk time, with its mandatory companions —
+    (i) physical HBM GB/s (PMC traffic / walk time), (ii) the compulsory bytes of a tick
+    (every player read once, 12 B, and written out once, 8 B) and how close the whole step is
+    to streaming just those, (iii) the tile width of the dominant kernel."""
+    walk_name = ("pair walk: kp_nx_init + kp_round x rounds + kp_late + kp_finish"
+                 if mode == "1v1" else "team walk: (kt_build + kt_f + kt_chase + kt_emit) x passes")
+    achieved = pairs * bytes_per_pair / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
+    compulsory = float(players) * (12 + 8)
+    return {
+        "bound": "hbm", "kernel": walk_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "algorithmic_bytes_per_launch": pairs * bytes_per_pair,
+        "launch": "one tick = one walk to quiescence (HIP events around the kernel sequence)",
+        "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+        "physical_gbs": (traffic / (walk_ms * 1e-3) / 1e9) if (traffic and walk_ms > 0) else None,
+        "compulsory_bytes_per_tick": compulsory,
+        "compulsory_frac": (compulsory / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_ms > 0 else None,
+        "tile_positions": 8192 if mode == "1v1" else 512,
+        "note": ("Mode R is a chain of dependent first-fit steps (%d passes of the cursor for "
+                 "the longest rating group); the engine replaces the per-pair rescans by "
+                 "%s, so it is bound by pass latency (kernel boundaries + LDS/VALU issue), "
+                 "not by HBM; see DESIGN.md") % (
+                    passes_max,
+                    "next[] pointers repaired incrementally" if mode == "1v1" else
+                    "per-pass F pointers (who the cursor picks after each player's lobby) "
+                    "computed for every queued player at once"),
+    }
 
 
 def parse():
@@ -51,6 +83,7 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "normal"])
     ap.add_argument("--mode", default="1v1", choices=["1v1", "5v5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency leg")
     ap.add_argument("--stream-qps", type=int, default=100_000)
     ap.add_argument("--stream-seconds", type=float, default=3.0)
@@ -240,10 +273,7 @@ def main():
         matched = float(s.item())
 
     if rank == 0:
-        walk_name = ("pair walk: kp_nx_init + kp_round x rounds + kp_late + kp_finish"
-                     if args.mode == "1v1" else "team walk: (kt_build + kt_f + kt_chase + kt_emit) x passes")
         k_ms = float(np.mean(walk_ms))
-        achieved = pairs * bytes_per_pair / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         try:
             tpath = args.traffic_json or os.path.join(
@@ -276,21 +306,11 @@ def main():
             "passes_max": last.stats["passes_max"],
             "kernel_ms": {"walk": k_ms, "bucket(count+scan+scatter)": float(np.mean(bucket_ms)),
                           "d2h+bookkeeping": float(np.mean(copy_ms))},
-            "roofline": {"bound": "hbm", "kernel": walk_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": pairs * bytes_per_pair,
-                         "launch": "one tick = one walk to quiescence (HIP events around the kernel sequence)",
-                         "note": ("Mode R is a chain of dependent first-fit steps (%d passes of the cursor for "
-                                  "the longest rating group); the engine replaces the per-pair rescans by "
-                                  "%s, so it is bound by pass latency (kernel boundaries + LDS/VALU issue), "
-                                  "not by HBM; see DESIGN.md") % (
-                                     last.stats["passes_max"],
-                                     "next[] pointers repaired incrementally" if args.mode == "1v1" else
-                                     "per-pass F pointers (who the cursor picks after each player's lobby) "
-                                     "computed for every queued player at once")},
+            "roofline": roofline_block(args.mode, pairs, bytes_per_pair, k_ms, elapsed / args.steps * 1e3, n,
+                                       last.stats["passes_max"], traffic),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, rating, cons, args.mode)
+            line["cpu_baseline"] = cpu_baseline(cfg, rating, cons, args.mode, budget_s=args.cpu_baseline_seconds)
         if world == 1 and not args.no_stream and args.mode == "1v1":
             scfg = make_config(modes, capacity=1 << 20, device=local_rank, timing=False)
             line["latency"] = stream_latency(lambda: Engine(scfg), args.stream_qps, args.stream_seconds,

@@ -1,0 +1,95 @@
+"""bench.py's reporting code without a GPU: (1) the `roofline` arithmetic on the numbers of the
+committed MI355X run, (2) a DRY RUN of bench.main() with the engine replaced by the fiber-shim
+build of the kernel source (tests/emu/) and torch.cuda stubbed — it checks that the ONE JSON
+line the driver parses has every field of the contract and consistent arithmetic.  Nothing here
+is a measurement; the numbers a dry run prints are discarded."""
+import ctypes as C
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from emu_engine import EmuEngine
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_roofline_block_reproduces_the_committed_line():
+    with open(os.path.join(ROOT, "profiles", "r01_bench_1m_1v1_final.json")) as f:
+        ref = json.loads(f.readline())
+    r = bench.roofline_block("1v1", ref["pairs_per_step"], 8, ref["kernel_ms"]["walk"], ref["ms_per_step"],
+                             1_000_000, ref["passes_max"], ref["roofline"]["traffic"])
+    assert r["achieved"] == pytest.approx(ref["roofline"]["achieved"], rel=1e-9)
+    assert r["frac"] == pytest.approx(ref["roofline"]["frac"], rel=1e-9)
+    assert r["algorithmic_bytes_per_launch"] == ref["roofline"]["algorithmic_bytes_per_launch"]
+    assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["bound"] == "hbm"
+    # companions of SURVEY.md section 8(d)
+    assert r["physical_gbs"] == pytest.approx(ref["roofline"]["traffic"] / (ref["kernel_ms"]["walk"] * 1e-3) / 1e9)
+    assert r["compulsory_bytes_per_tick"] == 20e6
+    assert r["compulsory_frac"] == pytest.approx(20e6 / (ref["ms_per_step"] * 1e-3) / 8e12)
+    assert r["frac_of_measured_copy_peak"] == pytest.approx(r["achieved"] / 6290.0)
+    assert r["tile_positions"] == 8192
+    none = bench.roofline_block("5v5", 1e6, 12, 0.0, 0.0, 1000, 3, None)
+    assert none["achieved"] == 0.0 and none["physical_gbs"] is None and none["tile_positions"] == 512
+
+
+class DryEngine(EmuEngine):
+    """EmuEngine + enqueue_device (under the shim 'device' memory is host memory)."""
+
+    def enqueue_device(self, d_rating, d_cons):
+        from microservice_matchmaking_amd._abi import MMEnqueueStats
+        fn = self._lib.mm_enqueue_device
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(MMEnqueueStats)]
+        fn.restype = C.c_int
+        first, st = C.c_uint32(), MMEnqueueStats()
+        assert fn(self._h, int(d_rating.numel()), C.c_void_p(d_rating.data_ptr()), C.c_void_p(d_cons.data_ptr()),
+                  C.byref(first), C.byref(st)) == 0
+        self.last_enqueue_stats = st.as_dict()
+        return int(first.value)
+
+
+@pytest.mark.parametrize("mode", ["1v1", "5v5"])
+def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
+    import torch
+    import microservice_matchmaking_amd as pkg
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(pkg, "Engine", DryEngine)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--players", "12000", "--steps", "2", "--warmup", "1", "--mode", mode,
+                                      "--stream-seconds", "0.1", "--stream-qps", "20000", "--cpu-baseline-seconds", "0.5"])
+    out = io.StringIO()
+    with redirect_stdout(out):
+        bench.main()
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("matched players/sec") and d["unit"] == "matched players/s"
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 2, 1)
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(d["matched_fraction"] * 12000 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "physical_gbs", "compulsory_bytes_per_tick",
+              "compulsory_frac", "tile_positions", "frac_of_measured_copy_peak"):
+        assert k in r, k
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert r["traffic"] is None                      # the PMC figure belongs to the 1M-player workload only
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    if mode == "1v1":
+        for leg in ("latency", "latency_mixed"):
+            assert d[leg]["p99_ms"] >= d[leg]["p50_ms"] >= 0 and d[leg]["enqueue_qps"] == 20000
+        assert set(np.asarray([len(d["latency_mixed"]["per_mode"])])) == {2}
