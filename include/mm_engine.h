@@ -14,8 +14,12 @@
  *   - returns 0 (MM_OK) or a negative mm_status; never throws, aborts or exits
  *     (a NIF crash would take the whole BEAM down — contrast the per-worker
  *     `restart: :transient` isolation at lib/application.ex:8-14);
- *   - one owner thread per engine, no internal locking (one GenServer owns one
- *     engine, as one Search.Worker owns one channel: lib/search/worker.ex:220-237);
+ *   - one owner per engine, no internal locking: calls on one engine never overlap (one
+ *     GenServer owns one engine, as one Search.Worker owns one channel:
+ *     lib/search/worker.ex:220-237).  The owner need not stay on one OS thread — a dirty NIF
+ *     runs on whichever dirty scheduler is free — so every entry point selects the engine's
+ *     HIP device itself (the current device is per-thread state in HIP) and restores the
+ *     caller's before it returns;
  *   - distinct engines are independent (own HIP stream, own device memory).
  *
  * The library has exactly one backend: hand-written HIP kernels for gfx950.

@@ -951,6 +951,37 @@ static double host_now_ms(void)
         }                                                 \
     } while (0)
 
+// HIP's current device is per-THREAD state, and the callers this ABI is shaped for do not keep a
+// thread: a dirty NIF runs on whichever dirty scheduler is free (native/mm_nif.c), the resource
+// destructor on whichever thread collects the handle.  Every entry point that touches the device
+// therefore selects the engine's device first and puts the caller's back on the way out, so an
+// engine on device k works from any thread and leaves the host program's own device alone.
+struct DeviceScope {
+    int prev, dev;
+    hipError_t err;
+    bool ok;
+    explicit DeviceScope(int d) : prev(-1), dev(d), err(hipSuccess), ok(true)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) {
+            err = hipSetDevice(dev);
+            ok = err == hipSuccess;
+        }
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define ON_ENGINE_DEVICE(e)                      \
+    DeviceScope _dev_scope((e)->cfg.device);     \
+    if (!_dev_scope.ok) {                        \
+        (e)->last_hip = (int)_dev_scope.err;      \
+        return MM_ERR_HIP;                       \
+    }
+
 extern "C" uint32_t mm_abi_version(void) { return MM_ABI_VERSION; }
 
 extern "C" const char* mm_strerror(int status)
@@ -1058,6 +1089,7 @@ static ModeDev make_mode_dev(const mm_mode_config& mc)
 extern "C" void mm_engine_destroy(mm_engine* e)
 {
     if (!e) return;
+    DeviceScope dev_scope(e->cfg.device);   // frees and the stream belong to the engine's device
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     (void)hipFree(e->d_q_rating);
     (void)hipFree(e->d_q_cons);
@@ -1162,7 +1194,11 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             return code;                                                 \
         }                                                                \
     } while (0)
-    CREATE_CHK(hipSetDevice(cfg->device));
+    DeviceScope dev_scope(cfg->device);        // the caller's device is put back when create returns
+    if (!dev_scope.ok) {
+        mm_engine_destroy(e);
+        return MM_ERR_HIP;
+    }
     CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) CREATE_CHK(hipEventCreate(&e->ev[i]));
     CREATE_CHK(hipMalloc((void**)&e->d_q_rating, e->n_chains * cap * sizeof(int32_t)));
@@ -1225,6 +1261,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
 extern "C" int mm_reset(mm_engine* e)
 {
     if (!e) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     std::fill(e->h_state.begin(), e->h_state.end(), (uint8_t)MM_ST_FREE);
     e->next_slot = 0;
     e->cancel_pending = 0;
@@ -1304,6 +1341,7 @@ extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const
                           const uint8_t* group, uint32_t* out_slot, mm_enqueue_stats* st)
 {
     if (!e || (n && (!rating || !cons))) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     const double t0 = host_now_ms();
     if (st) memset(st, 0, sizeof(*st));
     if (n == 0) return MM_OK;
@@ -1342,6 +1380,7 @@ extern "C" int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rati
                                  uint32_t* first_slot, mm_enqueue_stats* st)
 {
     if (!e || (n && (!d_rating || !d_cons))) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     const double t0 = host_now_ms();
     if (st) memset(st, 0, sizeof(*st));
     if (first_slot) *first_slot = e->next_slot;
@@ -1370,6 +1409,7 @@ extern "C" int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rati
 extern "C" int mm_cancel(mm_engine* e, uint32_t n, const uint32_t* slot)
 {
     if (!e || (n && !slot)) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     std::vector<uint32_t> live;
     live.reserve(n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -1587,6 +1627,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
 extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats)
 {
     if (!e || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     const double t0 = host_now_ms();
     const mm_config& cfg = e->cfg;
     const uint32_t G = cfg.n_groups;
@@ -1747,6 +1788,7 @@ static int fetch_chains(mm_engine* e)
 extern "C" int mm_queue_depth(mm_engine* e, uint32_t mode, uint32_t* per_group)
 {
     if (!e || !per_group || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     int rc = fetch_chains(e);
     if (rc) return rc;
     for (uint32_t g = 0; g < e->cfg.n_groups; ++g) per_group[g] = e->h_chains[mode * e->cfg.n_groups + g].len;
@@ -1757,6 +1799,7 @@ extern "C" int mm_lobby_state(mm_engine* e, uint32_t mode, uint32_t group, uint3
                               uint8_t* teams)
 {
     if (!e || !n || mode >= e->cfg.n_modes || group >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     int rc = fetch_chains(e);
     if (rc) return rc;
     const LobbyDev& lb = e->h_chains[mode * e->cfg.n_groups + group].lobby;
@@ -1812,6 +1855,7 @@ static unsigned long long snap_cfg_hash(const mm_config& c)
 extern "C" int mm_snapshot_size(mm_engine* e, uint64_t* bytes)
 {
     if (!e || !bytes) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     int rc = fetch_chains(e);
     if (rc) return rc;
     uint64_t n = sizeof(SnapHeader) + e->cfg.capacity + (uint64_t)e->n_chains * sizeof(ChainDev);
@@ -1823,6 +1867,7 @@ extern "C" int mm_snapshot_size(mm_engine* e, uint64_t* bytes)
 extern "C" int mm_snapshot(mm_engine* e, void* buf, uint64_t cap, uint64_t* written)
 {
     if (!e || !buf || !written) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     uint64_t need = 0;
     int rc = mm_snapshot_size(e, &need);                  // also refreshes h_chains
     if (rc) return rc;
@@ -1868,6 +1913,7 @@ extern "C" int mm_snapshot(mm_engine* e, void* buf, uint64_t cap, uint64_t* writ
 extern "C" int mm_restore(mm_engine* e, const void* buf, uint64_t bytes)
 {
     if (!e || !buf || bytes < sizeof(SnapHeader)) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
     const unsigned char* in = (const unsigned char*)buf;
     SnapHeader h;
     memcpy(&h, in, sizeof(h));

@@ -196,7 +196,14 @@ static double now_ms()
 }
 
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
+/* the current device is per-thread state, as in HIP: the engine's entry points must select theirs */
+static thread_local int t_device = 0;
+static int g_set_device_calls = 0;
+hipError_t hipSetDevice(int d) { t_device = d; ++g_set_device_calls; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
+extern "C" int emu_current_device(void) { return t_device; }
+extern "C" void emu_set_current_device(int d) { t_device = d; }
+extern "C" int emu_set_device_calls(void) { return g_set_device_calls; }
 hipError_t hipMalloc(void** p, size_t n)
 {
     /* poison so that reads of never-written device memory show up */

@@ -56,6 +56,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
