@@ -176,12 +176,17 @@ int mm_reset(mm_engine* e);
  *   non-integer / missing ratings, which the host routes by A1 on the exact value).
  *   out_slot[i] receives the engine handle of player i (stable until it is matched or
  *   cancelled), or 0xFFFFFFFF if the player was rejected (mode not configured, role not
- *   seatable).  Host pointers; the engine copies before returning. */
+ *   seatable).  Handles are the next n FREE slots of a ring of `capacity` slots, in ring
+ *   order: a player that waits for hours keeps its slot and later batches step over it
+ *   (MM_ERR_FULL only when fewer than n slots are free in the whole pool).
+ *   Host pointers; the engine copies before returning. */
 int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const uint32_t* cons,
                const uint8_t* group, uint32_t* out_slot, mm_enqueue_stats* st);
 
 /* Same, with rating/cons already resident in device memory (the benchmark path, and a
- * GPU-side codec's hand-off).  Slots are first_slot + i (mod capacity). */
+ * GPU-side codec's hand-off).  Slots are first_slot + i (mod capacity): this entry point needs
+ * that whole range free and returns MM_ERR_FULL otherwise (it does not step over waiting
+ * players — a service with long-waiting players ingests through mm_enqueue). */
 int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rating,
                       const uint32_t* d_cons, uint32_t* first_slot, mm_enqueue_stats* st);
 

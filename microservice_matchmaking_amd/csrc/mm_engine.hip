@@ -246,7 +246,9 @@ __global__ __launch_bounds__(BK_THREADS) void k_bucket_scatter(uint32_t n, const
                                                                const uint8_t* __restrict__ group, BucketCfg B,
                                                                uint32_t n_chains,
                                                                const uint32_t* __restrict__ wave_base,
-                                                               uint32_t first_slot, int32_t* __restrict__ q_rating,
+                                                               uint32_t first_slot,
+                                                               const uint32_t* __restrict__ slot_sel,
+                                                               int32_t* __restrict__ q_rating,
                                                                uint32_t* __restrict__ q_cons,
                                                                uint32_t* __restrict__ q_slot,
                                                                uint8_t* __restrict__ state,
@@ -271,7 +273,9 @@ __global__ __launch_bounds__(BK_THREADS) void k_bucket_scatter(uint32_t n, const
             cn = cons[i] & MM_CONS_USER_MASK;
             ch = dev_chain_of(B, rt, cn, group, i);
         }
-        const uint32_t slot = (uint32_t)(((unsigned long long)first_slot + i) % B.capacity);
+        // slot_sel: the host picked the free slots itself (the ring range held a waiting player)
+        const uint32_t slot = (slot_sel && valid) ? slot_sel[i]
+                                                  : (uint32_t)(((unsigned long long)first_slot + i) % B.capacity);
         if (valid && out_slot) out_slot[i] = (ch == BK_INVALID) ? MM_NO_SLOT : slot;
         unsigned long long todo = __ballot(ch != BK_INVALID);
         while (todo) {
@@ -887,6 +891,7 @@ struct mm_engine {
     uint32_t* d_in_cons;
     uint8_t* d_in_group;
     uint32_t* d_in_slot;       // also cancel staging
+    uint32_t* d_in_sel;        // slots the host picked (mm_enqueue stepping over waiting players)
     size_t in_cap;
     uint32_t* d_out_slots;
     float* d_out_score;
@@ -1103,6 +1108,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_in_cons);
     (void)hipFree(e->d_in_group);
     (void)hipFree(e->d_in_slot);
+    (void)hipFree(e->d_in_sel);
     (void)hipFree(e->d_out_slots);
     (void)hipFree(e->d_out_score);
     (void)hipFree(e->d_out_pass);
@@ -1279,18 +1285,21 @@ static int ensure_staging(mm_engine* e, size_t n)
     (void)hipFree(e->d_in_cons); e->d_in_cons = NULL;
     (void)hipFree(e->d_in_group); e->d_in_group = NULL;
     (void)hipFree(e->d_in_slot); e->d_in_slot = NULL;
+    (void)hipFree(e->d_in_sel); e->d_in_sel = NULL;
     e->in_cap = 0;
     HIPCHK(e, hipMalloc((void**)&e->d_in_rating, cap * sizeof(int32_t)));
     HIPCHK(e, hipMalloc((void**)&e->d_in_cons, cap * sizeof(uint32_t)));
     HIPCHK(e, hipMalloc((void**)&e->d_in_group, cap));
     HIPCHK(e, hipMalloc((void**)&e->d_in_slot, cap * sizeof(uint32_t)));
+    HIPCHK(e, hipMalloc((void**)&e->d_in_sel, cap * sizeof(uint32_t)));
     e->in_cap = cap;
     return MM_OK;
 }
 
 // Shared by both enqueue entry points; all pointers are device pointers.
 static int enqueue_device_impl(mm_engine* e, uint32_t n, const int32_t* d_rating, const uint32_t* d_cons,
-                               const uint8_t* d_group, uint32_t* d_out_slot, uint32_t* rejected, float* bucket_ms)
+                               const uint8_t* d_group, const uint32_t* d_slot_sel, uint32_t* d_out_slot,
+                               uint32_t* rejected, float* bucket_ms)
 {
     const uint32_t blocks = (n + BK_CHUNK - 1) / BK_CHUNK;
     const size_t rows = (size_t)blocks * BK_WAVES;
@@ -1310,7 +1319,7 @@ static int enqueue_device_impl(mm_engine* e, uint32_t n, const int32_t* d_rating
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(BK_THREADS), 0, e->stream, (uint32_t)rows, e->n_chains,
                        e->d_wave_hist, e->d_chains, e->cfg.capacity);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(BK_THREADS), 0, e->stream, n, d_rating, d_cons, d_group, B,
-                       e->n_chains, e->d_wave_hist, e->next_slot, e->d_q_rating, e->d_q_cons, e->d_q_slot,
+                       e->n_chains, e->d_wave_hist, e->next_slot, d_slot_sel, e->d_q_rating, e->d_q_cons, e->d_q_slot,
                        e->d_state, d_out_slot);
     HIPCHK(e, hipGetLastError());
     if (timing) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
@@ -1337,6 +1346,26 @@ static int ring_range_free(const mm_engine* e, uint32_t n)
     return 1;
 }
 
+// Slot allocation of mm_enqueue: the next n FREE slots in ring order from next_slot, stepping over
+// slots whose player is still waiting (a starving anchor may keep its slot for hours while the
+// ring wraps many times).  While nobody is in the way this is the plain range next_slot..+n-1
+// (`*contiguous`, no list needed).  0 = fewer than n free slots in the whole pool.
+static int pick_free_slots(const mm_engine* e, uint32_t n, std::vector<uint32_t>& sel, bool* contiguous)
+{
+    const uint32_t cap = e->cfg.capacity;
+    *contiguous = false;
+    if (n > cap) return 0;
+    if (ring_range_free(e, n)) { *contiguous = true; return 1; }
+    sel.clear();
+    sel.reserve(n);
+    uint32_t s = e->next_slot;
+    for (uint32_t seen = 0; seen < cap && sel.size() < n; ++seen) {
+        if (e->h_state[s] == MM_ST_FREE) sel.push_back(s);
+        s = s + 1u == cap ? 0u : s + 1u;
+    }
+    return sel.size() == n;
+}
+
 extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const uint32_t* cons,
                           const uint8_t* group, uint32_t* out_slot, mm_enqueue_stats* st)
 {
@@ -1345,19 +1374,23 @@ extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const
     const double t0 = host_now_ms();
     if (st) memset(st, 0, sizeof(*st));
     if (n == 0) return MM_OK;
-    if (!ring_range_free(e, n)) return MM_ERR_FULL;
+    std::vector<uint32_t> sel;
+    bool contiguous = false;
+    if (!pick_free_slots(e, n, sel, &contiguous)) return MM_ERR_FULL;
     if (group)
         for (uint32_t i = 0; i < n; ++i)
             if (group[i] >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
     int rc = ensure_staging(e, n);
     if (rc) return rc;
+    if (!contiguous)
+        HIPCHK(e, hipMemcpyAsync(e->d_in_sel, sel.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_in_rating, rating, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_in_cons, cons, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     if (group) HIPCHK(e, hipMemcpyAsync(e->d_in_group, group, n, hipMemcpyHostToDevice, e->stream));
     uint32_t rejected = 0;
     float bms = 0.f;
-    rc = enqueue_device_impl(e, n, e->d_in_rating, e->d_in_cons, group ? e->d_in_group : NULL, e->d_in_slot,
-                             &rejected, &bms);
+    rc = enqueue_device_impl(e, n, e->d_in_rating, e->d_in_cons, group ? e->d_in_group : NULL,
+                             contiguous ? NULL : e->d_in_sel, e->d_in_slot, &rejected, &bms);   // syncs: `sel` outlives the copy
     if (rc) return rc;
     std::vector<uint32_t> tmp;
     uint32_t* slots = out_slot;
@@ -1365,7 +1398,8 @@ extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const
     HIPCHK(e, hipMemcpy(slots, e->d_in_slot, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; ++i)
         if (slots[i] != MM_NO_SLOT) e->h_state[slots[i]] = MM_ST_LIVE;
-    e->next_slot = (uint32_t)(((unsigned long long)e->next_slot + n) % e->cfg.capacity);
+    e->next_slot = contiguous ? (uint32_t)(((unsigned long long)e->next_slot + n) % e->cfg.capacity)
+                              : (sel[n - 1] + 1u) % e->cfg.capacity;
     e->live_upper += n - rejected;
     if (st) {
         st->accepted = n - rejected;
@@ -1388,7 +1422,7 @@ extern "C" int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rati
     if (!ring_range_free(e, n)) return MM_ERR_FULL;
     uint32_t rejected = 0;
     float bms = 0.f;
-    int rc = enqueue_device_impl(e, n, d_rating, d_cons, NULL, NULL, &rejected, &bms);
+    int rc = enqueue_device_impl(e, n, d_rating, d_cons, NULL, NULL, NULL, &rejected, &bms);
     if (rc) return rc;
     // the host cannot see which players were rejected: the whole range stays reserved
     const uint32_t cap = e->cfg.capacity;

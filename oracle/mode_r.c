@@ -181,14 +181,21 @@ int mo_enqueue(mo_engine* e, uint32_t n, const int32_t* rating, const uint32_t* 
     double t0 = now_ms();
     const mm_config* cfg = &e->cfg;
     if (n > cfg->capacity) return MM_ERR_FULL;
-    for (uint32_t i = 0; i < n; ++i)
-        if (e->state[(e->next_slot + i) % cfg->capacity] != SLOT_FREE) return MM_ERR_FULL;
+    /* slot handles: the next n FREE slots in ring order from next_slot, stepping over slots whose
+     * player is still waiting (include/mm_engine.h, mm_enqueue); MM_ERR_FULL only when the pool
+     * has fewer than n free slots.  Handles are this engine's bookkeeping, not reference data. */
+    uint32_t nfree = 0;
+    for (uint32_t s = 0; s < cfg->capacity && nfree < n; ++s)
+        if (e->state[s] == SLOT_FREE) ++nfree;
+    if (nfree < n) return MM_ERR_FULL;
     if (group)
         for (uint32_t i = 0; i < n; ++i)
             if (group[i] >= cfg->n_groups) return MM_ERR_INVALID_ARG;
-    uint32_t acc = 0, rej = 0;
+    uint32_t acc = 0, rej = 0, cursor = e->next_slot;
     for (uint32_t i = 0; i < n; ++i) {
-        uint32_t slot = (e->next_slot + i) % cfg->capacity;
+        while (e->state[cursor] != SLOT_FREE) cursor = (cursor + 1u) % cfg->capacity;
+        uint32_t slot = cursor;
+        cursor = (cursor + 1u) % cfg->capacity;
         uint32_t c = cons[i] & MM_CONS_USER_MASK;
         uint32_t mode = MM_CONS_MODE(c), role = MM_CONS_ROLE(c);
         if (mode >= cfg->n_modes || role >= cfg->modes[mode].n_roles ||
@@ -205,7 +212,7 @@ int mo_enqueue(mo_engine* e, uint32_t n, const int32_t* rating, const uint32_t* 
         if (out_slot) out_slot[i] = slot;
         ++acc;
     }
-    e->next_slot = (e->next_slot + n) % cfg->capacity;
+    e->next_slot = cursor;
     e->next_seq += n;
     if (st) {
         memset(st, 0, sizeof(*st));

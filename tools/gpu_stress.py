@@ -25,6 +25,8 @@ SCALE = 1
 if os.environ.get("MM_STRESS_ENGINE", "gpu") == "emu_small":
     from emu_engine import EmuEngineSmall as Engine  # noqa: E402,F811
     SCALE = 16
+elif os.environ.get("MM_STRESS_ENGINE", "gpu") == "emu":      # product geometry under the shim: slow, sizes as on the GPU
+    from emu_engine import EmuEngine as Engine  # noqa: E402,F811
 
 
 def scaled(n):
