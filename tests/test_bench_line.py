@@ -93,3 +93,32 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
         for leg in ("latency", "latency_mixed"):
             assert d[leg]["p99_ms"] >= d[leg]["p50_ms"] >= 0 and d[leg]["enqueue_qps"] == 20000
         assert set(np.asarray([len(d["latency_mixed"]["per_mode"])])) == {2}
+
+
+def test_bench_two_ranks_dry_run_aggregates_over_ranks():
+    """`bench.py --gpus 2` as the driver launches it (one process per rank, env rendezvous on
+    127.0.0.1), with gloo standing in for RCCL: rank 0 prints the only line, n_gpus = 2, value =
+    players matched by BOTH ranks over the slowest rank's time."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_dryrun_worker.py")
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0",   # the shim has one device
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", "2", "--players", "12000", "--steps", "2",
+                                       "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-2000:]
+    lines0 = [ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and not [ln for ln in outs[1][0].decode().splitlines() if ln.startswith("{")]
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["pool_per_gpu"] == 12000
+    assert "cpu_baseline" not in d and "latency" not in d            # rank 0 at N=1 only
+    # both ranks' players are in `value` (pools differ by seed, so not exactly twice rank 0's)
+    per_rank = d["matched_fraction"] * 12000 / (d["ms_per_step"] * 1e-3)
+    assert 1.8 * per_rank < d["value"] < 2.2 * per_rank
