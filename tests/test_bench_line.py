@@ -122,3 +122,15 @@ def test_bench_two_ranks_dry_run_aggregates_over_ranks():
     # both ranks' players are in `value` (pools differ by seed, so not exactly twice rank 0's)
     per_rank = d["matched_fraction"] * 12000 / (d["ms_per_step"] * 1e-3)
     assert 1.8 * per_rank < d["value"] < 2.2 * per_rank
+
+
+def test_graft_entry_smoke_dry_run(monkeypatch, capsys):
+    """__graft_entry__.smoke() with the shim engine: the driver's pre-bench check is runnable code."""
+    import torch
+    import microservice_matchmaking_amd as pkg
+    import __graft_entry__ as entry
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(pkg, "Engine", DryEngine)
+    entry.smoke()
+    out = capsys.readouterr().out
+    assert out.count("smoke ok") == 2
