@@ -219,3 +219,22 @@ def test_codec_through_the_nif(beam):
     tag, (code, _) = beam.call("encode_lobby", b"5v5 ranked", 2, 5, pay[:9] + [b"[1]"])
     assert tag == "error" and code < 0
     beam.gc()
+
+
+def test_elixir_config_recipe_matches_the_c_struct():
+    """native/elixir/search_engine_config.ex spells the mm_config layout out field by field; the same
+    recipe in struct.pack form must give the bytes of the C struct (no hidden padding)."""
+    import struct
+    modes = [mode_1v1(window=25, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))]
+    cfg = make_config(modes, capacity=1 << 20, timing=False)
+    groups = b"".join(struct.pack("<ii", g[0], g[1]) for g in RATING_GROUPS) + b"\0" * 8 * (16 - len(RATING_GROUPS))
+    mb = b""
+    for m in modes:
+        quota = bytes(m["role_quota"]) + b"\0" * (8 - len(m["role_quota"]))
+        flags = (1 if m.get("region_filter") else 0) | (2 if m.get("party_filter") else 0)
+        mb += struct.pack("<5I", m["team_size"], m["teams"], m["window"], flags, len(m["role_quota"])) + quota
+    mb += b"\0" * 28 * (16 - len(modes))
+    blob = struct.pack("<II", 1, len(RATING_GROUPS)) + groups + struct.pack("<II", len(RATING_GROUPS) // 2 + 1, len(modes)) \
+        + mb + struct.pack("<IiI", 1 << 20, 0, 0)
+    assert len(blob) == C.sizeof(MMConfig) == 604
+    assert blob == cfg_bin(cfg)
