@@ -7,7 +7,6 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-import numpy as np
 
 from ._abi import EngineBase, MMConfig, MMEnqueueStats, MMError, bind
 

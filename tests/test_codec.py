@@ -3,7 +3,6 @@ libmm_engine.so, so these tests need no GPU.  The checker is Python's json modul
 UTF-8) plus oracle/literal_ref.find_rating_group_by_rating, the line-by-line restatement of
 lib/generic/worker.ex:46-53 (Erlang term order for non-numbers included)."""
 import json
-import time
 
 import numpy as np
 import pytest

@@ -8,7 +8,7 @@ import json
 import numpy as np
 import pytest
 
-from microservice_matchmaking_amd._abi import MMConfig, cons_make, decode_players, encode_lobby
+from microservice_matchmaking_amd._abi import MMConfig, decode_players, encode_lobby
 from microservice_matchmaking_amd.config import make_config, mode_1v1, mode_team
 from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5, make_pool
 from nif_beam import DIRTY_CPU, DIRTY_IO, BadArg, Beam, Charlist, Resource
