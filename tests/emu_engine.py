@@ -12,7 +12,7 @@ _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
 
 def load():
     subprocess.check_call(["make", "-C", _DIR, "--no-print-directory"], stdout=subprocess.DEVNULL)
-    lib = C.CDLL(os.path.join(_DIR, "libmm_engine_emu.so"))
+    lib = C.CDLL(os.environ.get("MM_EMU_LIB") or os.path.join(_DIR, "libmm_engine_emu.so"))   # see MM_EMU_SMALL_LIB
     return bind(lib, "mm_")
 
 
