@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency leg")
+    ap.add_argument("--concurrent-pools", type=int, default=0,
+                    help="opt-in extra leg (N=1 only): this many engines, each with its own pool of --players, "
+                         "ticking concurrently on their own streams; reported beside the main line, never as `value`")
     ap.add_argument("--stream-qps", type=int, default=100_000)
     ap.add_argument("--stream-seconds", type=float, default=3.0)
     ap.add_argument("--stream-tick-ms", type=float, default=10.0)
@@ -125,6 +128,54 @@ def cpu_baseline(cfg, rating, cons, mode_name, budget_s=20.0):
                      "note": "one thread per rating group = the reference's own parallelism"},
         "host_cores": os.cpu_count(),
     }
+
+
+def concurrent_pools(make_engine, pools, steps, make_inputs):
+    """Extra leg: the walk is bound by the latency of its passes and keeps well under half of the CUs
+    busy, so independent pools (other regions / shards of a service) on engines of their own
+    (own stream, own device memory: include/mm_engine.h) should overlap.  `pools` host threads, one
+    engine each, `steps` steps each (the ctypes calls release the GIL); matched players of all
+    pools over the wall time of the slowest."""
+    import threading
+    engines = [make_engine() for _ in range(pools)]
+    inputs = [make_inputs(k) for k in range(pools)]
+    matched = [0] * pools
+    errors = []
+    start = threading.Barrier(pools + 1)
+
+    def work(k):
+        try:
+            eng, (d_rating, d_cons) = engines[k], inputs[k]
+            eng.reset()
+            eng.enqueue_device(d_rating, d_cons)
+            eng.tick(0)                                   # warm-up
+            start.wait()
+            for _ in range(steps):
+                eng.reset()
+                eng.enqueue_device(d_rating, d_cons)
+                matched[k] += int(eng.tick(0).stats["players_matched"])
+        except Exception as ex:                           # report, never hang the barrier
+            errors.append(repr(ex))
+            start.abort()
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(pools)]
+    for t in threads:
+        t.start()
+    try:
+        start.wait()
+    except threading.BrokenBarrierError:
+        pass
+    t0 = time.perf_counter()
+    for t in threads:
+        t.join()
+    elapsed = time.perf_counter() - t0
+    for e in engines:
+        e.close()
+    if errors:
+        return {"pools": pools, "error": errors[0]}
+    return {"pools": pools, "steps": steps, "value": sum(matched) / elapsed, "unit": "matched players/s",
+            "ms_per_step_per_pool": elapsed / steps * 1e3,
+            "note": "k independent pools on one GPU, one engine and stream each; not the headline workload"}
 
 
 def stream_latency(make_engine, qps, seconds, tick_ms, label, seed=77, mode_weights=None, role_weights=None):
@@ -322,6 +373,16 @@ def main():
                                                    args.stream_tick_ms,
                                                    "70 %% 1v1 +-%d region filter / 30 %% 5v5 +-50 five roles" % args.window,
                                                    mode_weights=(70, 30), role_weights=ROLE_WEIGHTS_5V5)
+        if world == 1 and args.concurrent_pools > 1:
+            ccfg = make_config(modes, capacity=cap, device=local_rank, timing=False)
+
+            def pool_inputs(k):
+                kw = {"role_weights": ROLE_WEIGHTS_5V5} if args.mode == "5v5" else {}
+                r, c = make_pool(n, seed=101 + k, dist=args.dist, **kw)
+                return torch.from_numpy(r).cuda(), torch.from_numpy(c.view(np.int32)).cuda()
+
+            line["concurrent_pools"] = concurrent_pools(lambda: Engine(ccfg), args.concurrent_pools, args.steps,
+                                                        pool_inputs)
         print(json.dumps(line), flush=True)
     eng.close()
     if dist_on:

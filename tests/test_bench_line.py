@@ -39,8 +39,22 @@ def test_roofline_block_reproduces_the_committed_line():
     assert none["achieved"] == 0.0 and none["physical_gbs"] is None and none["tile_positions"] == 512
 
 
+import threading  # noqa: E402
+
+_SHIM_LOCK = threading.Lock()       # the fiber scheduler of the shim is one per process
+
+
 class DryEngine(EmuEngine):
-    """EmuEngine + enqueue_device (under the shim 'device' memory is host memory)."""
+    """EmuEngine + enqueue_device (under the shim 'device' memory is host memory).  The shim runs
+    one kernel at a time, so calls from bench.py's concurrent-pools threads take turns."""
+
+    def reset(self):
+        with _SHIM_LOCK:
+            return super().reset()
+
+    def tick(self, mode=0):
+        with _SHIM_LOCK:
+            return super().tick(mode)
 
     def enqueue_device(self, d_rating, d_cons):
         from microservice_matchmaking_amd._abi import MMEnqueueStats
@@ -48,8 +62,10 @@ class DryEngine(EmuEngine):
         fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(MMEnqueueStats)]
         fn.restype = C.c_int
         first, st = C.c_uint32(), MMEnqueueStats()
-        assert fn(self._h, int(d_rating.numel()), C.c_void_p(d_rating.data_ptr()), C.c_void_p(d_cons.data_ptr()),
-                  C.byref(first), C.byref(st)) == 0
+        with _SHIM_LOCK:
+            rc = fn(self._h, int(d_rating.numel()), C.c_void_p(d_rating.data_ptr()), C.c_void_p(d_cons.data_ptr()),
+                    C.byref(first), C.byref(st))
+        assert rc == 0
         self.last_enqueue_stats = st.as_dict()
         return int(first.value)
 
@@ -66,7 +82,8 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--players", "12000", "--steps", "2", "--warmup", "1", "--mode", mode,
-                                      "--stream-seconds", "0.1", "--stream-qps", "20000", "--cpu-baseline-seconds", "0.5"])
+                                      "--stream-seconds", "0.1", "--stream-qps", "20000", "--cpu-baseline-seconds", "0.5",
+                                      "--concurrent-pools", "2"])
     out = io.StringIO()
     with redirect_stdout(out):
         bench.main()
@@ -89,6 +106,8 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
     assert r["traffic"] is None                      # the PMC figure belongs to the 1M-player workload only
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    cp = d["concurrent_pools"]                      # opt-in leg: two engines, two host threads
+    assert cp["pools"] == 2 and "error" not in cp and cp["value"] > 0 and cp["steps"] == 2
     if mode == "1v1":
         for leg in ("latency", "latency_mixed"):
             assert d[leg]["p99_ms"] >= d[leg]["p50_ms"] >= 0 and d[leg]["enqueue_qps"] == 20000
