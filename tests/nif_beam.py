@@ -33,6 +33,10 @@ class Beam:
         from emu_engine import load as build_emu
         build_emu()                                               # libmm_engine_emu.so must exist first
         subprocess.check_call(["make", "-C", _DIR, "--no-print-directory"], stdout=subprocess.DEVNULL)
+        if backend == "hip":
+            # same loading order as the product binding (torch first: one HIP runtime per process)
+            from microservice_matchmaking_amd.engine import load_library
+            load_library()
         L = self.L = C.CDLL(os.path.join(_DIR, "mm_nif_%s.so" % backend))
         vp, term = C.c_void_p, C.c_size_t
         for name, res, args in (
