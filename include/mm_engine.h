@@ -186,7 +186,9 @@ int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const uint32_t* 
 /* Same, with rating/cons already resident in device memory (the benchmark path, and a
  * GPU-side codec's hand-off).  Slots are first_slot + i (mod capacity): this entry point needs
  * that whole range free and returns MM_ERR_FULL otherwise (it does not step over waiting
- * players — a service with long-waiting players ingests through mm_enqueue). */
+ * players — a service with long-waiting players ingests through mm_enqueue).  The host
+ * never sees which players of a device-resident batch were rejected (st->rejected counts
+ * them), so their slots stay reserved until mm_reset. */
 int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rating,
                       const uint32_t* d_cons, uint32_t* first_slot, mm_enqueue_stats* st);
 
