@@ -1650,11 +1650,12 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     HIPCHK(e, hipGetLastError());
     if (e->pair_debug)
         for (uint32_t g = 0; g < G; ++g)
-            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | kt_f chunk 1 cycles/pass: stage %u scan(wave 0) %u scan(workgroup) %u tail %u\n", g, e->h_tchains[g].fast,
+            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | kt_f chunk 1 cycles/pass: stage %u scan(wave 0) %u scan(workgroup) %u tail %u | F values written %u, changed after the first pass %u\n", g, e->h_tchains[g].fast,
                     e->h_tchains[g].m, e->h_tchains[g].passes, e->h_tchains[g].n_out, e->h_tchains[g].qlen,
                     e->h_tchains[g].dbg[6] & 1u, (e->h_tchains[g].dbg[6] >> 1) & 1u, (e->h_tchains[g].dbg[6] >> 2) & 1u, e->h_tchains[g].dbg[7],
                     e->h_tchains[g].dbg[0] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[1] / (e->h_tchains[g].passes + 1u),
-                    e->h_tchains[g].dbg[2] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[3] / (e->h_tchains[g].passes + 1u));
+                    e->h_tchains[g].dbg[2] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[3] / (e->h_tchains[g].passes + 1u),
+                    e->h_tchains[g].dbg[5], e->h_tchains[g].dbg[4]);
     return MM_OK;
 }
 
