@@ -5,7 +5,7 @@
  * the search/seed loop of `Matchmaking.Search.Worker` plus the external
  * `strategist.match.check` predicate it calls.  The reference has no FFI of its own
  * (it is 100 % Elixir); these are the entry points an Erlang dirty NIF would bind
- * (see INTEGRATION.md for the NIF stub and the Elixir module that replaces
+ * (native/mm_nif.c is that NIF, native/elixir/ the Elixir modules; INTEGRATION.md: how they replace
  * `Search.Worker.consume/5`).  Every export cites the reference code it replaces;
  * paths are relative to /root/reference/matchmaking/.
  *
