@@ -27,7 +27,7 @@ class EmuEngine(EngineBase):
 
 def load_small():
     subprocess.check_call(["make", "-C", _DIR, "--no-print-directory"], stdout=subprocess.DEVNULL)
-    # MM_EMU_SMALL_LIB: another build of the same source (tools/emu_asan_stress.sh: AddressSanitizer)
+    # MM_EMU_SMALL_LIB: another build of the same source (tests/emu_asan_stress.sh: AddressSanitizer)
     lib = C.CDLL(os.environ.get("MM_EMU_SMALL_LIB") or os.path.join(_DIR, "libmm_engine_emu_small.so"))
     return bind(lib, "mm_")
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Randomised differential stress on a real GPU: HIP engine vs oracle over many seeded
+"""Test infrastructure (it drives the oracle, so it lives under tests/).  Randomised differential stress on a real GPU: HIP engine vs oracle over many seeded
 scenarios (pool sizes that hit the LDS-resident walk, the tiled rounds and the hand-over
 between them; windows from 0 to wider than the rating span; 1..64 regions; multi-tick with
-arrivals and cancels).  Usage: python tools/gpu_stress.py [seconds] [seed] [team]
+arrivals and cancels).  Usage: python tests/stress.py [seconds] [seed] [team]
 
 MM_STRESS_ENGINE=emu_small runs the same scenarios without a GPU on the fiber-shim build of the
 kernel source with the tiny tile geometry (tests/emu/), pool sizes divided by 16 so that they
@@ -13,9 +13,10 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
 
 from helpers import assert_same_state, assert_same_tick  # noqa: E402
 from microservice_matchmaking_amd import Engine, cons_make, make_config, mode_1v1, mode_team  # noqa: E402

@@ -316,11 +316,11 @@ def test_gpu_5v5_10m_pool(gpu_cls, oracle_cls):
 
 
 def test_gpu_randomised_stress_short(gpu_cls, monkeypatch):
-    """Ten seconds of tools/gpu_stress.py: seeded random pools / predicates / multi-tick scripts
+    """Ten seconds of tests/stress.py: seeded random pools / predicates / multi-tick scripts
     with arrivals and cancels, every tick bit-exact against the oracle."""
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_stress.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress.py")
     spec = importlib.util.spec_from_file_location("gpu_stress", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
