@@ -139,14 +139,6 @@ def test_gpu_streaming_ticks_mixed_modes(gpu_cls, oracle_cls):
             assert_same_state(a, b, cfg, "tick %d" % tick)
 
 
-def test_gpu_stream_laps_the_slot_ring_around_waiting_players(gpu_cls, oracle_cls):
-    """mm_enqueue hands out the next FREE slots in ring order: a player that waits for hours keeps
-    its slot while the ring laps it (k_bucket_scatter with a host-picked slot list)."""
-    from helpers import run_wrapping_stream
-    laps, stepped = run_wrapping_stream(gpu_cls, oracle_cls, capacity=4096, ticks=150, per_tick=600)
-    assert laps > 10 and stepped > 20, (laps, stepped)
-
-
 def test_gpu_device_resident_enqueue(gpu_cls, oracle_cls):
     """mm_enqueue_device: inputs already in HBM (the benchmark path) == host-pointer path."""
     import torch
