@@ -927,6 +927,7 @@ struct mm_engine {
     uint32_t tk_chunk_stride;
     uint32_t team_batch;       // MM_TEAM_BATCH: passes launched per host look at the chains
     uint32_t team_cap;         // MM_TEAM_CAP: TeamParams.scan_cap
+    uint32_t dbg_last_w, dbg_last_c;   // MM_PAIR_DEBUG + MM_TEAM_BATCH=1: per-pass deltas of the F counters
     // host
     ChainDev* h_chains;        // pinned, n_chains
     uint32_t* h_counters;      // pinned, 2
@@ -1643,6 +1644,17 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         bool busy = false;
         for (uint32_t g = 0; g < G; ++g)
             if (e->h_tchains[g].fast && !e->h_tchains[g].done) busy = true;
+        if (e->pair_debug && e->team_batch == 1u) {   // MM_TEAM_BATCH=1: one line per pass, the longest chain
+            uint32_t gl = 0;
+            for (uint32_t g = 1; g < G; ++g)
+                if (e->h_tchains[g].m > e->h_tchains[gl].m) gl = g;
+            const TeamChain& tc = e->h_tchains[gl];
+            if (guard == 0) { e->dbg_last_w = 0; e->dbg_last_c = 0; }
+            fprintf(stderr, "[mm-team-pass] g%u pass %u queued %u lobbies %u F written %u changed %u\n", gl, tc.passes,
+                    tc.qlen, tc.n_vis, tc.dbg[5] - e->dbg_last_w, tc.dbg[4] - e->dbg_last_c);
+            e->dbg_last_w = tc.dbg[5];
+            e->dbg_last_c = tc.dbg[4];
+        }
         if (!busy) break;
     }
     hipLaunchKernelGGL(kt_fin_scatter, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
