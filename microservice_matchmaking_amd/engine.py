@@ -7,7 +7,6 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-
 from ._abi import EngineBase, MMConfig, MMEnqueueStats, MMError, bind
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
