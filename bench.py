@@ -1,32 +1,44 @@
 #!/usr/bin/env python
-"""bench.py — matched players/sec over a 1M-player pool (BASELINE.json metric), on N MI355X.
+"""bench.py — matched players/sec over a synthetic pool (BASELINE.json metric), on N MI355X.
 
 One "step" = one pass of the hot path over one batch of synthetic input: reset the engine,
-enqueue a 1,000,000-player pool that is ALREADY RESIDENT IN HBM (bucketing kernels), run
-the search to quiescence (walk kernel), and bring the match list back to the host (the
-service needs it to publish lobbies).  Workload = BASELINE.json configs[1]:
-"1v1, 1M players, +-25 rating + region filter on 1 MI355X", seeded synthetic pool
-(uniform integer ratings on [0, 5000], 8 regions, arrival order = index).
+enqueue the rank's share of the pool, ALREADY RESIDENT IN HBM (bucketing kernels), run the
+search to quiescence (walk kernels), and bring the match list back to the host (the service
+needs it to publish lobbies).
 
-N > 1: rating-group chains are independent (reference lib/application.ex:26-40), so the
-path shards with no data-path collective; every rank owns one engine and its own 1M-player
-pool (another seed) — weak scaling.  RCCL is used only for the barrier and the max/sum of
-the timing/throughput scalars.
+N = 1: BASELINE.json configs[1] — "1v1, 1M players, +-25 rating + region filter on 1 MI355X",
+seeded synthetic pool (uniform integer ratings on [0, 5000], 8 regions, arrival order = index).
+
+N > 1: BASELINE.json configs[3] — ONE 10M-player 1v1 pool sharded across the N GPUs.  Every
+rank generates the same seeded pool and keeps the chains = (game mode, rating group) that
+`sharding.ChainSharding` gives it (reference lib/application.ex:26-40: one queue, one lobby
+table and one worker per rating group; lib/models/lobby_state.ex:74-83: the stored lobby is
+selected by game mode).  Chains never interact, so there is NO data-path collective: RCCL is
+used for the barriers and for gathering the result scalars / digests.  `value` = matched players
+of the whole pool / the slowest rank's time (strong scaling: the pool is fixed as N grows); it
+is bounded by the heaviest chain (the first rating group holds 30 % of a uniform pool), and with
+7 chains on 8 ranks one rank idles — reported as such (`config.sharding`).  The union of the
+ranks' emission lists is checked against the oracle's digest of the same pool
+(tests/golden/shared_pool_digests.json, tools/make_shared_pool_digests.py) — `exactness`.
+Secondary keys, never `value`: `weak_scaling` (every rank its own 1M pool) and `latency_mixed`
+(BASELINE configs[4]: the 100k players/s 70/30 stream, chains sharded over the ranks).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the walk (the search proper: for a 1v1
 mode the pair path's kernel sequence kp_nx_init, kp_round x rounds (one launch per pass of the
-cursor), kp_late, kp_finish — DESIGN.md §4; for team modes the single kernel k_walk):
+cursor), kp_late, kp_finish — DESIGN.md §4; for team modes kt_build/kt_f/kt_chase/kt_emit per pass):
 achieved = algorithmic bytes / HIP-event time of that sequence on the engine's stream,
 algorithmic bytes = pair evaluations of the reference algorithm (the oracle's count, which
 the engine reproduces bit-exactly) x 8 B (rating + cons of the candidate).
 The engine does NOT touch every such pair — it keeps next[] pointers instead of rescanning —
-so `traffic` (HBM bytes from rocprofv3 PMC passes, profiles/) is far below the algorithmic
-bytes; the walk is bound by the latency of ~300-600 dependent passes, not by HBM
-(DESIGN.md §5).  `cpu_baseline` = the oracle
-(oracle/mode_r.c, a C port of the reference's sequential search, in-memory — an upper
-bound on what the BEAM service could do) timed on this box's host cores.
+so `traffic` (HBM bytes from rocprofv3 PMC passes, profiles/) is unrelated to the algorithmic
+bytes; the walk is bound by the latency of several hundred dependent passes, not by HBM
+(DESIGN.md §5): `roofline.latency_floor_ms` = passes x one dependent kernel boundary (measured
+in this run) is the ceiling the design can be held to, `frac_of_latency_ceiling` how close it is.
+`cpu_baseline` = the oracle (oracle/mode_r.c, a C port of the reference's sequential search,
+in-memory — an upper bound on what the BEAM service could do) timed on this box's host cores.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -40,19 +52,50 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # MI355X_MICROARCH.md: measured copy ceiling (SURVEY.md §8(d) asks for both)
 BYTES_PER_PAIR = 8
+CSRC = os.path.join(ROOT, "microservice_matchmaking_amd", "csrc")
+DIGESTS = os.path.join(ROOT, "tests", "golden", "shared_pool_digests.json")
 
 
-def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passes_max, traffic):
+def kernel_source_hash():
+    """Hash of the kernel sources a traffic / profile file was measured on."""
+    h = hashlib.blake2b(digest_size=8)
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".inc", ".h")):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def load_traffic(path, players, mode):
+    """PMC traffic of one tick from profiles/ — only if it was measured on THESE kernel sources
+    and this workload; otherwise (None, why)."""
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+    except Exception:
+        return None, "no PMC file %s" % os.path.basename(path)
+    if tj.get("workload_players") != players or tj.get("mode") != mode:
+        return None, "PMC file is for another workload"
+    if tj.get("source_hash") != kernel_source_hash():
+        return None, "PMC file %s was measured on other kernel sources (hash %s, now %s): re-run tools/make_traffic.py" % (
+            os.path.basename(path), tj.get("source_hash"), kernel_source_hash())
+    return tj.get("walk_hbm_bytes_per_tick"), None
+
+
+def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passes_max, traffic,
+                   boundary_us=None, traffic_note=None):
     """The `roofline` object of the bench line (pure arithmetic; tests/test_bench_line.py).
     SURVEY.md §8(d): achieved = algorithmic bytes / walk time, with its mandatory companions —
     (i) physical HBM GB/s (PMC traffic / walk time), (ii) the compulsory bytes of a tick
     (every player read once, 12 B, and written out once, 8 B) and how close the whole step is
-    to streaming just those, (iii) the tile width of the dominant kernel."""
+    to streaming just those, (iii) the tile width of the dominant kernel — and the latency
+    ceiling of a chain of dependent passes (passes x one kernel boundary)."""
     walk_name = ("pair walk: kp_nx_init + kp_round x rounds + kp_late + kp_finish"
                  if mode == "1v1" else "team walk: (kt_build + kt_f + kt_chase + kt_emit) x passes")
     achieved = pairs * bytes_per_pair / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
     compulsory = float(players) * (12 + 8)
-    return {
+    floor_ms = passes_max * boundary_us * 1e-3 if boundary_us else None
+    out = {
         "bound": "hbm", "kernel": walk_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "algorithmic_bytes_per_launch": pairs * bytes_per_pair,
@@ -62,37 +105,50 @@ def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passe
         "compulsory_bytes_per_tick": compulsory,
         "compulsory_frac": (compulsory / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_ms > 0 else None,
         "tile_positions": 8192 if mode == "1v1" else 512,
+        "boundary_us": boundary_us,
+        "latency_floor_ms": floor_ms,
+        "frac_of_latency_ceiling": (floor_ms / walk_ms) if (floor_ms and walk_ms > 0) else None,
+        "us_per_pass": (walk_ms * 1e3 / passes_max) if passes_max else None,
         "note": ("Mode R is a chain of dependent first-fit steps (%d passes of the cursor for "
                  "the longest rating group); the engine replaces the per-pair rescans by "
                  "%s, so it is bound by pass latency (kernel boundaries + LDS/VALU issue), "
-                 "not by HBM; see DESIGN.md") % (
+                 "not by HBM; latency_floor_ms = passes x one dependent kernel boundary is the "
+                 "ceiling of a one-launch-per-pass design; see DESIGN.md") % (
                     passes_max,
                     "next[] pointers repaired incrementally" if mode == "1v1" else
                     "per-pass F pointers (who the cursor picks after each player's lobby) "
                     "computed for every queued player at once"),
     }
+    if traffic is None and traffic_note:
+        out["traffic_note"] = traffic_note
+    return out
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--players", type=int, default=1_000_000)
+    ap.add_argument("--steps", type=int, default=120, help="default: a timed region of about 2 s at N=1")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--players", type=int, default=None,
+                    help="pool size; default 1,000,000 at N=1 (cfg-2) and 10,000,000 at N>1 (cfg-4, one shared pool)")
     ap.add_argument("--window", type=int, default=25)
     ap.add_argument("--dist", default="uniform", choices=["uniform", "normal"])
     ap.add_argument("--mode", default="1v1", choices=["1v1", "5v5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time budget of the cpu_baseline leg")
-    ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency leg")
-    ap.add_argument("--concurrent-pools", type=int, default=0,
-                    help="opt-in extra leg (N=1 only): this many engines, each with its own pool of --players, "
+    ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency legs")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (weak_scaling at N>1, shared_pool_n1 and concurrent_pools at N=1)")
+    ap.add_argument("--concurrent-pools", type=int, default=2,
+                    help="secondary leg (N=1 only): this many engines, each with its own pool of --players, "
                          "ticking concurrently on their own streams; reported beside the main line, never as `value`")
+    ap.add_argument("--shared-players", type=int, default=10_000_000, help="pool of the shared_pool_n1 leg (cfg-4 on one GPU)")
+    ap.add_argument("--weak-players", type=int, default=1_000_000, help="pool per rank of the weak_scaling leg (N>1)")
     ap.add_argument("--stream-qps", type=int, default=100_000)
     ap.add_argument("--stream-seconds", type=float, default=3.0)
     ap.add_argument("--stream-tick-ms", type=float, default=10.0)
     ap.add_argument("--traffic-json", default=None,
-                    help="optional {'k_walk_hbm_bytes_per_launch': ...} from a rocprofv3 --pmc pass")
+                    help="optional PMC summary written by tools/make_traffic.py (default: profiles/traffic_latest*.json)")
     return ap.parse_args()
 
 
@@ -130,10 +186,41 @@ def cpu_baseline(cfg, rating, cons, mode_name, budget_s=20.0):
     }
 
 
+def measure_boundary_us(torch, n=400):
+    """One dependent kernel boundary on this GPU: a hipGraph of n trivial dependent launches,
+    HIP-event time / n (MI355X_MICROARCH.md `boundary`: ~1.45 us).  The walk is one launch per
+    pass of the cursor, so passes x this is the floor of the design."""
+    try:
+        x = torch.zeros(256, device="cuda", dtype=torch.int32)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                x.add_(1)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(n):
+                    x.add_(1)
+            g.replay()
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                g.replay()
+                e1.record(s)
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) * 1e3 / n
+                best = t if best is None or t < best else best
+        return float(best)
+    except Exception:
+        return None
+
+
 def concurrent_pools(make_engine, pools, steps, make_inputs):
-    """Extra leg: the walk is bound by the latency of its passes and keeps well under half of the CUs
+    """Secondary leg: the walk is bound by the latency of its passes and keeps well under half of the CUs
     busy, so independent pools (other regions / shards of a service) on engines of their own
-    (own stream, own device memory: include/mm_engine.h) should overlap.  `pools` host threads, one
+    (own stream, own device memory: include/mm_engine.h) overlap.  `pools` host threads, one
     engine each, `steps` steps each (the ctypes calls release the GIL); matched players of all
     pools over the wall time of the slowest."""
     import threading
@@ -175,79 +262,75 @@ def concurrent_pools(make_engine, pools, steps, make_inputs):
         return {"pools": pools, "error": errors[0]}
     return {"pools": pools, "steps": steps, "value": sum(matched) / elapsed, "unit": "matched players/s",
             "ms_per_step_per_pool": elapsed / steps * 1e3,
-            "note": "k independent pools on one GPU, one engine and stream each; not the headline workload"}
+            "note": "k independent pools on one GPU, one engine and stream each; not the headline workload "
+                    "(measured sweet spot: 2 pools, profiles/r02_concurrent_pools_*.json)"}
 
 
-def stream_latency(make_engine, qps, seconds, tick_ms, label, seed=77, mode_weights=None, role_weights=None):
-    """Second half of BASELINE.json's metric: match latency at a fixed enqueue rate.  Players
-    arrive as a Poisson stream (`qps`), every `tick_ms` of REAL time the arrivals of the period
-    are enqueued (host pointers, so the H2D copy and the bucketing kernels are inside) and every
-    mode is ticked once; a matched player's latency = wall time at which its lobby came back
-    from mm_tick minus its arrival time.  Reported: p50 / p99 / max, matched players/s, backlog.
-    `mode_weights` mixes the engine's modes (BASELINE cfg-5: 70 % 1v1 / 30 % 5v5); players of
-    mode 1 draw a role from `role_weights`."""
-    import time as _t
-    from microservice_matchmaking_amd.synth import make_pool
-    eng = make_engine()
-    n_modes = int(eng.cfg.n_modes)
-    rng = np.random.default_rng(seed)
-    n_ticks = int(seconds * 1000.0 / tick_ms)
-    arrival = np.zeros(eng.cfg.capacity, dtype=np.float64)     # by slot
-    lat = [[] for _ in range(n_modes)]
-    tick_cost = []
-    matched = 0
-
-    def batch(n, sd):
-        rating, cons = make_pool(n, seed=sd, mode_weights=mode_weights, role_weights=role_weights)
-        if mode_weights:
-            cons = np.where((cons & 0xF) == 0, cons & ~np.uint32(0xF << 16), cons).astype(np.uint32)
-        return rating, cons
-
-    # warm the kernels up outside the clock
-    r0, c0 = batch(2000, seed)
-    eng.enqueue(r0, c0)
+def stream_leg(search, dist, rank, world, qps, seconds, tick_ms, label, seed=77, mode_weights=None, role_weights=None):
+    """Second half of BASELINE.json's metric: match latency at a fixed enqueue rate
+    (microservice_matchmaking_amd/stream.py).  Every rank sees the whole stream and keeps its
+    chains; rank 0 gathers the latencies of all ranks."""
+    from microservice_matchmaking_amd.sharding import union_digest
+    from microservice_matchmaking_amd.stream import latency_summary, run_stream, stream_batch, stream_schedule
+    n_modes = int(search.cfg.n_modes)
+    r0, c0 = stream_batch(2000, seed, mode_weights, role_weights)   # warm the kernels up outside the clock
+    search.enqueue(r0, c0)
     for md in range(n_modes):
-        eng.tick(md)
-    eng.reset()
-    t_start = _t.perf_counter()
-    for k in range(n_ticks):
-        t_open, t_close = k * tick_ms * 1e-3, (k + 1) * tick_ms * 1e-3
-        n = int(rng.poisson(qps * tick_ms * 1e-3))
-        rating, cons = batch(n, seed + 1 + k)
-        ts = np.sort(rng.uniform(t_open, t_close, size=n))
-        while _t.perf_counter() - t_start < t_close:            # the period has to be over
-            pass
-        t0 = _t.perf_counter()
-        slots = eng.enqueue(rating, cons)
-        arrival[slots] = ts
-        for md in range(n_modes):
-            m = eng.tick(md)
-            t1 = _t.perf_counter()
-            if len(m):
-                s_ = m.slots.ravel()
-                lat[md].append((t1 - t_start) - arrival[s_])
-                matched += s_.size
-        tick_cost.append(_t.perf_counter() - t0)
-    elapsed = _t.perf_counter() - t_start
-    depth = [int(eng.queue_depth(md).sum()) for md in range(n_modes)]
-    eng.close()
+        search.tick(md)
+    search.engine.reset()
+    sched = stream_schedule(qps, seconds, tick_ms, seed)
+    if dist is not None:
+        dist.barrier()
+    res = run_stream(search, sched, mode_weights=mode_weights, role_weights=role_weights, realtime=True)
+    mine = {c: d for c, d in res["digests"].items() if search.sharding.chain_owner[c] == rank}
+    part = {"real": res["real"], "floor": res["floor"], "matched": res["matched"], "elapsed": res["elapsed"],
+            "tick_cost": res["tick_cost"], "depth": [d.tolist() for d in res["depth"]], "digests": mine}
+    parts = [part]
+    if dist is not None:
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+    if rank != 0:
+        return None
+    cat = lambda key, md: np.concatenate([p[key][md] for p in parts])
     per_mode = []
     for md in range(n_modes):
-        v = np.concatenate(lat[md]) if lat[md] else np.zeros(1)
-        per_mode.append({"p50_ms": float(np.percentile(v, 50) * 1e3), "p99_ms": float(np.percentile(v, 99) * 1e3),
-                         "max_ms": float(v.max() * 1e3), "matched_players": int(v.size if lat[md] else 0),
-                         "backlog_players": depth[md]})
-    allv = np.concatenate([np.concatenate(x) for x in lat if x]) if any(lat) else np.zeros(1)
-    out = {"enqueue_qps": qps, "tick_ms": tick_ms, "seconds": seconds, "mode": label,
-           "p50_ms": float(np.percentile(allv, 50) * 1e3), "p99_ms": float(np.percentile(allv, 99) * 1e3),
-           "max_ms": float(allv.max() * 1e3), "matched_players_per_s": matched / elapsed,
-           "tick_cost_ms_mean": float(np.mean(tick_cost) * 1e3), "tick_cost_ms_p99": float(np.percentile(tick_cost, 99) * 1e3),
-           "backlog_players": int(sum(depth)), "kept_up": bool(elapsed < seconds * 1.05),
-           "note": "latency floor = half a tick period + the tick; a chain whose anchor nobody fits waits for "
-                   "arrivals (reference behaviour, docs/MATCH_CHECK.md section 4)"}
+        s = latency_summary(cat("real", md), cat("floor", md))
+        s["backlog_players"] = int(sum(sum(p["depth"][md]) for p in parts))
+        per_mode.append(s)
+    real = np.concatenate([cat("real", md) for md in range(n_modes)])
+    floor = np.concatenate([cat("floor", md) for md in range(n_modes)])
+    elapsed = max(p["elapsed"] for p in parts)
+    cost = np.concatenate([p["tick_cost"] for p in parts])
+    digests = {}
+    for p in parts:
+        digests.update(p["digests"])
+    out = {"enqueue_qps": qps, "tick_ms": tick_ms, "seconds": seconds, "mode": label, "ranks": world}
+    out.update(latency_summary(real, floor))
+    out.update({
+        "matched_players_per_s": sum(p["matched"] for p in parts) / elapsed,
+        "tick_cost_ms_mean": float(np.mean(cost) * 1e3), "tick_cost_ms_p99": float(np.percentile(cost, 99) * 1e3),
+        "backlog_players": int(sum(s["backlog_players"] for s in per_mode)),
+        "kept_up": bool(elapsed < seconds * 1.05),
+        "emission_digest": union_digest(digests),
+        "note": "floor_* = end of the tick period in which the player was matched minus its arrival: the wait for "
+                "fitting partners to ARRIVE (reference behaviour, docs/MATCH_CHECK.md section 4: a chain whose "
+                "anchor nobody fits waits for arrivals), what an engine with a free tick would give; "
+                "engine_added = real - floor"})
     if n_modes > 1:
         out["per_mode"] = per_mode
     return out
+
+
+def workload_key(mode, players, window, dist_name, seed=1):
+    return "%s/%d/w%d/%s/seed%d" % (mode, players, window, dist_name, seed)
+
+
+def expected_digest(key):
+    try:
+        with open(DIGESTS) as f:
+            return json.load(f).get(key)
+    except Exception:
+        return None
 
 
 def main():
@@ -258,134 +341,242 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    dist_on = world > 1
-    if dist_on:
+    dist = None
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from microservice_matchmaking_amd import Engine, make_config, mode_1v1, mode_team
+    from microservice_matchmaking_amd.sharding import (ChainSharding, ShardedSearch, chain_weights, rating_groups,
+                                                       tick_digests, union_digest)
     from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5, make_pool
 
-    n = args.players
     if args.mode == "1v1":
         modes = [mode_1v1(window=args.window, region_filter=True)]
-        rating, cons = make_pool(n, seed=1 + rank, dist=args.dist)
+        pool_kw = {}
         bytes_per_pair = BYTES_PER_PAIR
-        workload = "1v1, %d players, +-%d rating + region filter (8 regions), %s ratings" % (n, args.window, args.dist)
+        window = args.window
+        describe = lambda n: "1v1, %d players, +-%d rating + region filter (8 regions), %s ratings" % (n, args.window, args.dist)
     else:
         modes = [mode_team(5, 2, 50, (1, 1, 1, 1, 1))]
-        rating, cons = make_pool(n, seed=1 + rank, dist=args.dist, role_weights=ROLE_WEIGHTS_5V5)
+        pool_kw = {"role_weights": ROLE_WEIGHTS_5V5}
         bytes_per_pair = 12
-        workload = "5v5 team balance, %d players, +-50 rating + 5 roles, %s ratings" % (n, args.dist)
-    cap = 1
-    while cap < n:
-        cap <<= 1
-    cfg = make_config(modes, capacity=cap, device=local_rank, timing=True)
+        window = 50
+        describe = lambda n: "5v5 team balance, %d players, +-50 rating + 5 roles, %s ratings" % (n, args.dist)
 
-    d_rating = torch.from_numpy(rating).cuda()
-    d_cons = torch.from_numpy(cons.view(np.int32)).cuda()
-    eng = Engine(cfg)
-
-    def step():
-        eng.reset()
-        eng.enqueue_device(d_rating, d_cons)
-        m = eng.tick(0)
-        return m, dict(eng.last_enqueue_stats)
+    def pow2(n):
+        cap = 1
+        while cap < max(n, 2):
+            cap <<= 1
+        return cap
 
     def fence():
         torch.cuda.synchronize()
-        if dist_on:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    walk_ms, bucket_ms, copy_ms = [], [], []
-    last = None
-    for _ in range(args.steps):
-        last, est = step()
-        walk_ms.append(last.stats["walk_ms"])
-        bucket_ms.append(est["bucket_ms"])
-        copy_ms.append(last.stats["copy_ms"])
-    fence()
-    elapsed = time.perf_counter() - t0
+    def shared_pool_run(n, w, r, steps, warmup, timing=True):
+        """One pool of n players, sharded over w ranks by chain; this process is rank r of them.
+        Returns (elapsed of the timed steps on this rank, last tick, per-step timers, my digests,
+        the sharding, players this rank holds).  The caller brackets it with fence()."""
+        rating, cons = make_pool(n, seed=1, dist=args.dist, **pool_kw)
+        cfg1 = make_config(modes, capacity=16, device=local_rank, timing=False)
+        sh = ChainSharding(1, cfg1.n_groups, w, chain_weights(cfg1, rating, cons)[0])
+        grp = rating_groups(cfg1, rating)
+        idx = np.nonzero(sh.chain_owner[0][grp.astype(np.int64)] == r)[0]
+        timers = {"walk": [], "bucket": [], "copy": []}
+        digests, last = {}, None
+        elapsed = 0.0
+        if idx.size:
+            cfg = make_config(modes, capacity=pow2(idx.size), device=local_rank, timing=timing)
+            d_rating = torch.from_numpy(rating[idx]).cuda()
+            d_cons = torch.from_numpy(cons[idx].view(np.int32)).cuda()
+            eng = Engine(cfg)
 
-    matched = float(last.stats["players_matched"]) * args.steps
-    pairs = float(last.stats["pairs"])
-    if dist_on:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([matched], device="cuda", dtype=torch.float64)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        matched = float(s.item())
+            def step():
+                eng.reset()
+                first = eng.enqueue_device(d_rating, d_cons)
+                return first, eng.tick(0), dict(eng.last_enqueue_stats)
+            for _ in range(warmup):
+                step()
+        fence()
+        t0 = time.perf_counter()
+        if idx.size:
+            for _ in range(steps):
+                first, last, est = step()
+                timers["walk"].append(last.stats["walk_ms"])
+                timers["bucket"].append(est["bucket_ms"])
+                timers["copy"].append(last.stats["copy_ms"])
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        fence()
+        if idx.size:
+            ids = idx[(last.slots.astype(np.int64) - first) % int(cfg.capacity)] if len(last) else \
+                np.zeros(last.slots.shape, np.int64)
+            digests = {c: d for c, d in tick_digests(0, cfg.n_groups, ids, last.group).items()
+                       if sh.chain_owner[c] == r}
+            eng.close()
+        return elapsed, last, timers, digests, sh, int(idx.size), (rating, cons)
 
+    boundary_us = measure_boundary_us(torch) if rank == 0 else None
+    tdefault = os.path.join(ROOT, "profiles",
+                            "traffic_latest.json" if args.mode == "1v1" else "traffic_latest_%s.json" % args.mode)
+
+    # ------------------------------------------------------------------ the main leg
+    n = args.players if args.players else (1_000_000 if world == 1 else 10_000_000)
+    elapsed, last, timers, digests, sh, n_mine, (rating, cons) = shared_pool_run(n, world, rank, args.steps, args.warmup)
+    st = last.stats if last is not None else {"players_matched": 0, "pairs": 0, "passes_max": 0}
+    part = {"rank": rank, "elapsed": elapsed, "players": n_mine, "matched_per_step": int(st["players_matched"]),
+            "pairs": int(st["pairs"]), "passes_max": int(st["passes_max"]),
+            "walk_ms": float(np.mean(timers["walk"])) if timers["walk"] else 0.0,
+            "bucket_ms": float(np.mean(timers["bucket"])) if timers["bucket"] else 0.0,
+            "copy_ms": float(np.mean(timers["copy"])) if timers["copy"] else 0.0, "digests": digests}
+    parts = [part]
+    if dist is not None:
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+
+    line = None
     if rank == 0:
-        k_ms = float(np.mean(walk_ms))
-        traffic = None
-        try:
-            tpath = args.traffic_json or os.path.join(
-                ROOT, "profiles", "traffic_latest.json" if args.mode == "1v1" else "traffic_latest_%s.json" % args.mode)
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("workload_players") == n and tj.get("mode") == args.mode:
-                traffic = tj.get("walk_hbm_bytes_per_tick")
-        except Exception:
-            pass
+        slow = max(parts, key=lambda p: p["elapsed"])            # the slowest rank bounds the pool
+        elapsed_max = slow["elapsed"]
+        matched_step = sum(p["matched_per_step"] for p in parts)
+        pairs = float(sum(p["pairs"] for p in parts))
+        got = {}
+        for p in parts:
+            got.update(p["digests"])
+        key = workload_key(args.mode, n, window, args.dist)
+        want = expected_digest(key)
+        traffic, tnote = (None, "PMC traffic is per single-GPU tick; not collected for the sharded run")
+        if world == 1:
+            traffic, tnote = load_traffic(args.traffic_json or tdefault, n, args.mode)
+        step_ms = elapsed_max / args.steps * 1e3
         line = {
-            "metric": "matched players/sec over 1M-player pool",
-            "value": matched / elapsed,
+            "metric": "matched players/sec over 1M-player pool" if world == 1 else
+                      "matched players/sec over one 10M-player pool sharded across the GPUs",
+            "value": matched_step * args.steps / elapsed_max,
             "unit": "matched players/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": workload, "rating_groups": 7, "pool_per_gpu": n,
-                       "sharding": "one engine + own pool per GPU; no data-path collective",
-                       "step": "reset + enqueue(device-resident) + search to quiescence + match list D2H"},
-            "matched_fraction": float(last.stats["players_matched"]) / n,
-            "pair_evals_per_s": pairs / (k_ms * 1e-3) if k_ms > 0 else None,
+            "config": {
+                "workload": describe(n) if world == 1 else
+                            "%s — ONE pool sharded across %dxMI355X by (game mode, rating group)" % (describe(n), world),
+                "baseline_config": "configs[1]" if (world == 1 and n == 1_000_000) else
+                                   ("configs[3]" if (world > 1 and n == 10_000_000 and args.mode == "1v1") else "custom"),
+                "rating_groups": 7,
+                "sharding": dict(sh.describe(), **{
+                    "collective": "none on the data path (chains never interact: reference lib/application.ex:26-40, "
+                                  "lib/models/lobby_state.ex:74-83); RCCL only for barriers and result gathering",
+                    "no_halo_allgather": "a chain has ONE open lobby and ONE cursor (lobby_state.ex:90-91); every pass "
+                                         "depends on the pass before, so a rating-bucket split of a chain would hop "
+                                         "devices once per pass — there is no order-free boundary to exchange "
+                                         "(DESIGN.md section 7)",
+                    "per_rank": [{"rank": p["rank"], "players": p["players"], "matched_players": p["matched_per_step"],
+                                  "ms_per_step": p["elapsed"] / args.steps * 1e3, "passes_max": p["passes_max"]}
+                                 for p in parts]}),
+                "step": "reset + enqueue(device-resident share) + search to quiescence + match list D2H"},
+            "exactness": {"emission_digest": union_digest(got), "oracle_digest": want,
+                          "ok": (union_digest(got) == want) if want else None, "key": key,
+                          "what": "blake2b over every chain's emission list (global arrival indices, publish order); "
+                                  "oracle_digest = the CPU oracle on the same pool (tests/golden/shared_pool_digests.json)"},
+            "matched_fraction": matched_step / float(n),
+            "pair_evals_per_s": pairs / (slow["walk_ms"] * 1e-3) if slow["walk_ms"] > 0 else None,
             "pairs_per_step": pairs,
-            "passes_max": last.stats["passes_max"],
-            "kernel_ms": {"walk": k_ms, "bucket(count+scan+scatter)": float(np.mean(bucket_ms)),
-                          "d2h+bookkeeping": float(np.mean(copy_ms))},
-            "roofline": roofline_block(args.mode, pairs, bytes_per_pair, k_ms, elapsed / args.steps * 1e3, n,
-                                       last.stats["passes_max"], traffic),
+            "passes_max": max(p["passes_max"] for p in parts),
+            "kernel_ms": {"walk": slow["walk_ms"], "bucket(count+scan+scatter)": slow["bucket_ms"],
+                          "d2h+bookkeeping": slow["copy_ms"], "of_rank": slow["rank"]},
+            "roofline": roofline_block(args.mode, pairs, bytes_per_pair, slow["walk_ms"], step_ms, n,
+                                       max(p["passes_max"] for p in parts), traffic, boundary_us, tnote),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, rating, cons, args.mode, budget_s=args.cpu_baseline_seconds)
-        if world == 1 and not args.no_stream and args.mode == "1v1":
-            scfg = make_config(modes, capacity=1 << 20, device=local_rank, timing=False)
-            line["latency"] = stream_latency(lambda: Engine(scfg), args.stream_qps, args.stream_seconds,
-                                             args.stream_tick_ms, "1v1 +-%d, region filter" % args.window)
-            # BASELINE cfg-5 on one GPU: the same stream with 70 % 1v1 / 30 % 5v5 (roles as cfg-3)
-            mcfg = make_config([mode_1v1(window=args.window, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
-                               capacity=1 << 20, device=local_rank, timing=False)
-            line["latency_mixed"] = stream_latency(lambda: Engine(mcfg), args.stream_qps, args.stream_seconds,
-                                                   args.stream_tick_ms,
-                                                   "70 %% 1v1 +-%d region filter / 30 %% 5v5 +-50 five roles" % args.window,
-                                                   mode_weights=(70, 30), role_weights=ROLE_WEIGHTS_5V5)
-        if world == 1 and args.concurrent_pools > 1:
-            ccfg = make_config(modes, capacity=cap, device=local_rank, timing=False)
+            cfg_cpu = make_config(modes, capacity=pow2(n), device=local_rank, timing=False)
+            line["cpu_baseline"] = cpu_baseline(cfg_cpu, rating, cons, args.mode, budget_s=args.cpu_baseline_seconds)
+    del rating, cons
 
-            def pool_inputs(k):
-                kw = {"role_weights": ROLE_WEIGHTS_5V5} if args.mode == "5v5" else {}
-                r, c = make_pool(n, seed=101 + k, dist=args.dist, **kw)
-                return torch.from_numpy(r).cuda(), torch.from_numpy(c.view(np.int32)).cuda()
+    # ------------------------------------------------------------------ secondary legs (never `value`)
+    if not args.no_secondary:
+        if world == 1:
+            # cfg-4's pool on ONE GPU: the N=1 point of the strong-scaling curve of `--gpus N`
+            n10 = args.shared_players
+            if n10 and n10 != n:
+                steps10 = max(2, min(args.steps, 8))
+                el, l10, tm, dg, _, _, _ = shared_pool_run(n10, 1, 0, steps10, 1)
+                k10 = workload_key(args.mode, n10, window, args.dist)
+                line["shared_pool_n1"] = {
+                    "workload": describe(n10), "value": float(l10.stats["players_matched"]) * steps10 / el,
+                    "unit": "matched players/s", "ms_per_step": el / steps10 * 1e3, "steps": steps10,
+                    "passes_max": int(l10.stats["passes_max"]), "walk_ms": float(np.mean(tm["walk"])),
+                    "exact": (union_digest(dg) == expected_digest(k10)) if expected_digest(k10) else None}
+            if args.concurrent_pools > 1:
+                ccfg = make_config(modes, capacity=pow2(n), device=local_rank, timing=False)
 
-            line["concurrent_pools"] = concurrent_pools(lambda: Engine(ccfg), args.concurrent_pools, args.steps,
-                                                        pool_inputs)
+                def pool_inputs(k):
+                    r, c = make_pool(n, seed=101 + k, dist=args.dist, **pool_kw)
+                    return torch.from_numpy(r).cuda(), torch.from_numpy(c.view(np.int32)).cuda()
+
+                line["concurrent_pools"] = concurrent_pools(lambda: Engine(ccfg), args.concurrent_pools,
+                                                            max(2, min(args.steps, 20)), pool_inputs)
+        else:
+            # weak scaling: every rank its own 1M pool (what round 1 reported as the value)
+            r1, c1 = make_pool(args.weak_players, seed=1 + rank, dist=args.dist, **pool_kw)
+            wcfg = make_config(modes, capacity=pow2(args.weak_players), device=local_rank, timing=False)
+            d_r, d_c = torch.from_numpy(r1).cuda(), torch.from_numpy(c1.view(np.int32)).cuda()
+            wsteps = max(2, min(args.steps, 20))
+            with Engine(wcfg) as weng:
+                def wstep():
+                    weng.reset()
+                    weng.enqueue_device(d_r, d_c)
+                    return weng.tick(0)
+                wstep()
+                fence()
+                t0 = time.perf_counter()
+                wm = 0
+                for _ in range(wsteps):
+                    wm += int(wstep().stats["players_matched"])
+                fence()
+                wel = time.perf_counter() - t0
+            tt = torch.tensor([wel, 0.0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ss = torch.tensor([float(wm)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                line["weak_scaling"] = {"value": float(ss.item()) / float(tt[0].item()), "unit": "matched players/s",
+                                        "pool_per_gpu": args.weak_players, "steps": wsteps,
+                                        "ms_per_step": float(tt[0].item()) / wsteps * 1e3,
+                                        "note": "every rank its own pool (independent pools of a node); "
+                                                "secondary, never `value`"}
+
+    if not args.no_stream:
+        w25 = mode_1v1(window=args.window, region_filter=True)
+        mix_w = np.outer([0.7, 0.3], [0.30, 0.10, 0.10, 0.10, 0.10, 0.10, 0.20])   # expected share of every chain
+        if world == 1 and args.mode == "1v1":
+            scfg = make_config([w25], capacity=1 << 20, device=local_rank, timing=False)
+            with ShardedSearch(scfg, Engine, 0, 1) as s1:
+                line["latency"] = stream_leg(s1, None, 0, 1, args.stream_qps, args.stream_seconds, args.stream_tick_ms,
+                                             "1v1 +-%d, region filter" % args.window)
+        if args.mode == "1v1":
+            # BASELINE cfg-5: 70 % 1v1 / 30 % 5v5 (roles as cfg-3), chains = (mode, group) over the ranks
+            mcfg = make_config([w25, mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 20, device=local_rank, timing=False)
+            with ShardedSearch(mcfg, Engine, rank, world, mix_w) as sm:
+                res = stream_leg(sm, dist, rank, world, args.stream_qps, args.stream_seconds, args.stream_tick_ms,
+                                 "70 %% 1v1 +-%d region filter / 30 %% 5v5 +-50 five roles" % args.window,
+                                 mode_weights=(70, 30), role_weights=ROLE_WEIGHTS_5V5)
+                if rank == 0:
+                    res["sharding"] = sm.sharding.describe()
+                    line["latency_mixed"] = res
+
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    eng.close()
-    if dist_on:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

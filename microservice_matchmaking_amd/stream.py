@@ -1,0 +1,106 @@
+"""The streaming leg of the path (BASELINE cfg-5): a Poisson arrival stream, one enqueue and one
+tick per mode every tick period, on one engine or on one rank's share of the chains.
+
+What replaces what: the arrivals of a period are the deliveries `Search.Worker` would receive
+(reference lib/search/worker.ex:352-358), a tick is `consume/5` run to quiescence for one mode
+(worker.ex:291-324).  The stream is driven by TICK COUNT, not by wall time, so what is matched
+in which tick is deterministic (and is compared with the oracle in tests/); wall time only
+enters the reported latency.
+
+Two latencies per matched player:
+  real   wall time at which its lobby came back from mm_tick, minus its arrival time;
+  floor  end of the tick period in which it was matched, minus its arrival time — what an
+         engine with a free tick would give.  It is the time the player waited for fitting
+         partners to ARRIVE (reference behaviour: a lobby waits until a fitting player is
+         delivered, docs/MATCH_CHECK.md §4); real - floor is what the engine adds.
+"""
+from __future__ import annotations
+
+import hashlib
+import time
+
+import numpy as np
+
+from .synth import make_pool
+
+
+def stream_batch(n, seed, mode_weights=None, role_weights=None):
+    """One period's arrivals.  Players of mode 0 (1v1) carry no role."""
+    rating, cons = make_pool(n, seed=seed, mode_weights=mode_weights, role_weights=role_weights)
+    if mode_weights:
+        cons = np.where((cons & 0xF) == 0, cons & ~np.uint32(0xF << 16), cons).astype(np.uint32)
+    return rating, cons
+
+
+def stream_schedule(qps, seconds, tick_ms, seed):
+    """[(t_open, t_close, n, batch seed, sorted arrival times)] — the same on every rank."""
+    rng = np.random.default_rng(seed)
+    n_ticks = int(seconds * 1000.0 / tick_ms)
+    out = []
+    for k in range(n_ticks):
+        t_open, t_close = k * tick_ms * 1e-3, (k + 1) * tick_ms * 1e-3
+        n = int(rng.poisson(qps * tick_ms * 1e-3))
+        out.append((t_open, t_close, n, seed + 1 + k, np.sort(rng.uniform(t_open, t_close, size=n))))
+    return out
+
+
+def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=True):
+    """Drive `search` (a sharding.ShardedSearch: one engine + the chains this rank owns) through
+    the schedule.  Returns a dict with per-mode latency arrays (real, floor), matched players,
+    per-tick cost and a digest per chain of everything it emitted, in order."""
+    cfg = search.cfg
+    n_modes, n_groups = int(cfg.n_modes), int(cfg.n_groups)
+    total = sum(s[2] for s in schedule)
+    arrival = np.zeros(total, dtype=np.float64)                 # by global arrival index
+    real = [[] for _ in range(n_modes)]
+    floor = [[] for _ in range(n_modes)]
+    hashers = {(m, g): hashlib.blake2b(digest_size=16) for m in range(n_modes) for g in range(n_groups)}
+    emitted = {key: 0 for key in hashers}
+    tick_cost = []
+    matched = 0
+    first = 0
+    t_start = time.perf_counter()
+    for (t_open, t_close, n, sd, ts) in schedule:
+        rating, cons = stream_batch(n, sd, mode_weights, role_weights)
+        arrival[first:first + n] = ts
+        if realtime:
+            while time.perf_counter() - t_start < t_close:      # the period has to be over
+                pass
+        t0 = time.perf_counter()
+        search.enqueue(rating, cons, first_global_index=first)
+        first += n
+        for md in range(n_modes):
+            m = search.tick(md)
+            t1 = time.perf_counter()
+            if len(m):
+                ids = search.global_ids(m)
+                flat = ids.ravel()
+                real[md].append((t1 - t_start) - arrival[flat])
+                floor[md].append(t_close - arrival[flat])
+                matched += flat.size
+                for g in np.unique(m.group):
+                    sel = np.ascontiguousarray(ids[m.group == g], dtype="<i8")
+                    hashers[(md, int(g))].update(sel.tobytes())
+                    emitted[(md, int(g))] += int(sel.shape[0])
+        tick_cost.append(time.perf_counter() - t0)
+    elapsed = time.perf_counter() - t_start
+    depth = [search.engine.queue_depth(md).astype(np.int64) for md in range(n_modes)]
+    cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0)
+    return {
+        "real": [cat(x) for x in real], "floor": [cat(x) for x in floor],
+        "matched": matched, "elapsed": elapsed, "tick_cost": np.asarray(tick_cost),
+        "depth": depth, "digests": {k: h.hexdigest() for k, h in hashers.items()}, "lobbies": emitted,
+        "arrivals": total,
+    }
+
+
+def latency_summary(real, floor):
+    """p50 / p99 / max of the real latency and of the arrival-limited floor, in ms."""
+    if real.size == 0:
+        return {"p50_ms": None, "p99_ms": None, "max_ms": None, "floor_p50_ms": None, "floor_p99_ms": None,
+                "matched_players": 0}
+    return {"p50_ms": float(np.percentile(real, 50) * 1e3), "p99_ms": float(np.percentile(real, 99) * 1e3),
+            "max_ms": float(real.max() * 1e3),
+            "floor_p50_ms": float(np.percentile(floor, 50) * 1e3), "floor_p99_ms": float(np.percentile(floor, 99) * 1e3),
+            "engine_added_p99_ms": float(np.percentile(real - floor, 99) * 1e3),
+            "matched_players": int(real.size)}

@@ -37,6 +37,23 @@ def test_roofline_block_reproduces_the_committed_line():
     assert r["tile_positions"] == 8192
     none = bench.roofline_block("5v5", 1e6, 12, 0.0, 0.0, 1000, 3, None)
     assert none["achieved"] == 0.0 and none["physical_gbs"] is None and none["tile_positions"] == 512
+    assert none["latency_floor_ms"] is None and "traffic_note" not in none
+    # the latency ceiling of a one-launch-per-pass design: passes x one dependent kernel boundary
+    lat = bench.roofline_block("1v1", 7e7, 8, 16.0, 17.0, 1_000_000, 600, None, boundary_us=1.5, traffic_note="stale")
+    assert lat["latency_floor_ms"] == pytest.approx(0.9) and lat["frac_of_latency_ceiling"] == pytest.approx(0.9 / 16.0)
+    assert lat["us_per_pass"] == pytest.approx(16000.0 / 600) and lat["traffic_note"] == "stale"
+
+
+def test_traffic_file_is_refused_when_the_kernel_sources_changed(tmp_path):
+    good = {"workload_players": 1000, "mode": "1v1", "walk_hbm_bytes_per_tick": 5.0, "source_hash": bench.kernel_source_hash()}
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps(good))
+    assert bench.load_traffic(str(p), 1000, "1v1") == (5.0, None)
+    assert bench.load_traffic(str(p), 2000, "1v1")[0] is None
+    p.write_text(json.dumps(dict(good, source_hash="0000")))
+    t, why = bench.load_traffic(str(p), 1000, "1v1")
+    assert t is None and "other kernel sources" in why
+    assert bench.load_traffic(str(tmp_path / "missing.json"), 1000, "1v1")[0] is None
 
 
 import threading  # noqa: E402
@@ -83,7 +100,7 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--players", "12000", "--steps", "2", "--warmup", "1", "--mode", mode,
                                       "--stream-seconds", "0.1", "--stream-qps", "20000", "--cpu-baseline-seconds", "0.5",
-                                      "--concurrent-pools", "2"])
+                                      "--concurrent-pools", "2", "--shared-players", "20000"])
     out = io.StringIO()
     with redirect_stdout(out):
         bench.main()
@@ -103,7 +120,11 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
               "compulsory_frac", "tile_positions", "frac_of_measured_copy_peak"):
         assert k in r, k
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
-    assert r["traffic"] is None                      # the PMC figure belongs to the 1M-player workload only
+    assert r["traffic"] is None and "traffic_note" in r   # the PMC figure belongs to the 1M-player workload only
+    ex = d["exactness"]                              # the emission digest against the oracle's (committed) digest
+    assert ex["ok"] is True and ex["emission_digest"] == ex["oracle_digest"] and ex["key"].startswith(mode + "/12000/")
+    sp = d["shared_pool_n1"]                         # cfg-4's pool on one GPU (here: 20000 players)
+    assert sp["exact"] is True and sp["value"] > 0 and "20000 players" in sp["workload"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     cp = d["concurrent_pools"]                      # opt-in leg: two engines, two host threads
@@ -111,13 +132,18 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
     if mode == "1v1":
         for leg in ("latency", "latency_mixed"):
             assert d[leg]["p99_ms"] >= d[leg]["p50_ms"] >= 0 and d[leg]["enqueue_qps"] == 20000
+            assert d[leg]["floor_p99_ms"] >= d[leg]["floor_p50_ms"] >= 0     # the arrival-limited floor beside it
+            assert len(d[leg]["emission_digest"]) == 32
         assert set(np.asarray([len(d["latency_mixed"]["per_mode"])])) == {2}
 
 
-def test_bench_two_ranks_dry_run_aggregates_over_ranks():
-    """`bench.py --gpus 2` as the driver launches it (one process per rank, env rendezvous on
-    127.0.0.1), with gloo standing in for RCCL: rank 0 prints the only line, n_gpus = 2, value =
-    players matched by BOTH ranks over the slowest rank's time."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_ranks_dry_run_shards_one_pool(world, oracle_cls):
+    """`bench.py --gpus N` as the driver launches it (one process per rank, env rendezvous on
+    127.0.0.1), with gloo standing in for RCCL: rank 0 prints the only line; the workload is ONE
+    pool sharded by chain (BASELINE cfg-4's shape), value = players matched by ALL ranks over the
+    slowest rank's time, and the union of the ranks' emission lists has the oracle's digest.
+    world 8: seven chains on eight ranks, one rank idles and still takes part in the barriers."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -125,22 +151,48 @@ def test_bench_two_ranks_dry_run_aggregates_over_ranks():
         port = sk.getsockname()[1]
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_dryrun_worker.py")
     procs = []
-    for rank in (0, 1):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0",   # the shim has one device
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",   # the shim has one device
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", "2", "--players", "12000", "--steps", "2",
-                                       "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
-    outs = [p.communicate(timeout=600) for p in procs]
+        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", str(world), "--players", "12000", "--steps", "2",
+                                       "--warmup", "1", "--weak-players", "6000", "--stream-seconds", "0.1",
+                                       "--stream-qps", "20000"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=900) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e.decode()[-2000:]
     lines0 = [ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")]
-    assert len(lines0) == 1 and not [ln for ln in outs[1][0].decode().splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1
+    for o, _ in outs[1:]:
+        assert not [ln for ln in o.decode().splitlines() if ln.startswith("{")]
     d = json.loads(lines0[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["pool_per_gpu"] == 12000
+    assert d["n_gpus"] == world and d["scaling"] == "strong"
+    assert "sharded across %dxMI355X" % world in d["config"]["workload"] and "12000 players" in d["config"]["workload"]
     assert "cpu_baseline" not in d and "latency" not in d            # rank 0 at N=1 only
-    # both ranks' players are in `value` (pools differ by seed, so not exactly twice rank 0's)
-    per_rank = d["matched_fraction"] * 12000 / (d["ms_per_step"] * 1e-3)
-    assert 1.8 * per_rank < d["value"] < 2.2 * per_rank
+    sh = d["config"]["sharding"]
+    assert sh["key"] == "(game mode, rating group)" and "none" in sh["collective"] and "no_halo_allgather" in sh
+    assert len(sh["per_rank"]) == world and sum(p["players"] for p in sh["per_rank"]) == 12000
+    assert sh["idle_ranks"] == ([7] if world == 8 else [])
+    for r in sh["idle_ranks"]:
+        assert sh["per_rank"][r]["players"] == 0 and sh["per_rank"][r]["matched_players"] == 0
+    # every rank's players are in `value`; the slowest rank's clock is the pool's
+    assert d["matched_fraction"] * 12000 == pytest.approx(sum(p["matched_players"] for p in sh["per_rank"]))
+    assert d["ms_per_step"] == pytest.approx(max(p["ms_per_step"] for p in sh["per_rank"]))
+    assert d["value"] == pytest.approx(d["matched_fraction"] * 12000 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    ex = d["exactness"]
+    assert ex["ok"] is True and ex["emission_digest"] == ex["oracle_digest"]
+    assert d["weak_scaling"]["pool_per_gpu"] == 6000 and d["weak_scaling"]["value"] > 0
+    lm = d["latency_mixed"]                                           # cfg-5: the two-mode stream, chains over the ranks
+    assert lm["ranks"] == world and lm["sharding"]["idle_ranks"] == [] and len(lm["per_mode"]) == 2
+    # the stream's emission on N ranks is the single oracle engine's
+    from microservice_matchmaking_amd.config import make_config, mode_1v1, mode_team
+    from microservice_matchmaking_amd.sharding import ShardedSearch, union_digest
+    from microservice_matchmaking_amd.stream import run_stream, stream_schedule
+    from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5
+    cfg = make_config([mode_1v1(window=25, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 20)
+    with ShardedSearch(cfg, oracle_cls, 0, 1) as one:
+        ref = run_stream(one, stream_schedule(20000, 0.1, 10.0, 77), mode_weights=(70, 30),
+                         role_weights=ROLE_WEIGHTS_5V5, realtime=False)
+    assert lm["emission_digest"] == union_digest(ref["digests"])
 
 
 def test_graft_entry_smoke_dry_run(monkeypatch, capsys):

@@ -6,7 +6,11 @@ Usage: python tools/make_traffic.py <fetch.csv> <write.csv> <mode> <players> <ti
 The CSVs are the output of tools/rocpd_pmc.py (kernel,counter,dispatches,sum)."""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (bench.py refuses a file measured on other kernel sources)
 
 
 def load(path, prefixes):
@@ -28,6 +32,7 @@ def main(fetch_csv, write_csv, mode, players, ticks, prefixes):
                "dispatches_per_tick": f.get(k, w.get(k, (0, 0)))[1] / ticks} for k in sorted(set(f) | set(w))}
     print(json.dumps({
         "workload_players": int(players), "mode": mode, "ticks_profiled": ticks,
+        "source_hash": kernel_source_hash(),
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) of bench.py; sums over "
                   "the walk's kernels (%s*) divided by the ticks" % "*, ".join(prefixes),
         "fetch_size_kb_per_tick_raw": fetch, "write_size_kb_per_tick_raw": write,
