@@ -227,6 +227,16 @@ int mm_matches(mm_engine* e, uint32_t first, uint32_t count, uint32_t* slots, fl
  * players seated in the open lobby. per_group has cfg.n_groups entries. */
 int mm_queue_depth(mm_engine* e, uint32_t mode, uint32_t* per_group);
 
+/* The queue of (mode, group), head first: the deliveries still waiting in
+ * `matchmaking.queues.<group>` in the order the broker would hand them out — arrival order,
+ * rotated by the requeues of rejected players (requeue_player/5, lib/search/worker.ex:239-248 ->
+ * Requeue.Worker.consume/4, lib/requeue/worker.ex:51-54: a rejected player re-enters at the TAIL).
+ * The reference can only see the depth (AMQP.Queue.status); the engine exposes the order so that
+ * requeue ordering can be checked directly after every tick (and so that an operator can see
+ * who is waiting).  In: *n = capacity of `slots` (entries); out: *n = queue length; at most
+ * min(capacity, length) handles are written.  `slots` may be NULL to ask for the length. */
+int mm_queue_slots(mm_engine* e, uint32_t mode, uint32_t group, uint32_t* n, uint32_t* slots);
+
 /* The open lobby of (mode, group) — the record LobbyState.get_state/4 would pop
  * (lib/models/lobby_state.ex:61-104).  Writes up to MM_MAX_LOBBY (slot, team) pairs in
  * team order; *n = seated players. */

@@ -89,7 +89,7 @@ def cons_make(mode=0, region=0, party=0, role=0):
 # cross-checks this list against include/mm_engine.h.
 ABI_FUNCTIONS = [
     "engine_create", "engine_destroy", "reset", "find_rating_group", "enqueue", "cancel",
-    "tick", "matches", "queue_depth", "lobby_state",
+    "tick", "matches", "queue_depth", "queue_slots", "lobby_state",
 ]
 PRODUCT_ONLY_FUNCTIONS = ["abi_version", "strerror", "config_default", "enqueue_device",
                           "last_hip_error"]
@@ -178,6 +178,8 @@ def bind(lib, prefix):
     f("matches").restype = C.c_int
     f("queue_depth").argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     f("queue_depth").restype = C.c_int
+    f("queue_slots").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p, C.c_void_p]
+    f("queue_slots").restype = C.c_int
     f("lobby_state").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p, C.c_void_p, C.c_void_p]
     f("lobby_state").restype = C.c_int
     if hasattr(lib, prefix + "snapshot"):                 # the oracle does not mirror these
@@ -295,6 +297,15 @@ class EngineBase:
         out = np.zeros(self.cfg.n_groups, dtype=np.uint32)
         self._check(self._fn("queue_depth")(self._h, mode, _ptr(out)), "queue_depth")
         return out
+
+    def queue_slots(self, mode, group):
+        """The queue of (mode, group), head first (requeue order, worker.ex:239-248)."""
+        n = C.c_uint32(0)
+        self._check(self._fn("queue_slots")(self._h, mode, group, C.byref(n), None), "queue_slots")
+        out = np.zeros(int(n.value), dtype=np.uint32)
+        n2 = C.c_uint32(out.size)
+        self._check(self._fn("queue_slots")(self._h, mode, group, C.byref(n2), _ptr(out)), "queue_slots")
+        return out[:min(int(n2.value), out.size)]
 
     def snapshot(self) -> bytes:
         """The whole pool (queues in order, stored lobbies, ActiveUser mirror, slot allocator)."""

@@ -1842,6 +1842,25 @@ extern "C" int mm_queue_depth(mm_engine* e, uint32_t mode, uint32_t* per_group)
     return MM_OK;
 }
 
+extern "C" int mm_queue_slots(mm_engine* e, uint32_t mode, uint32_t group, uint32_t* n, uint32_t* slots)
+{
+    if (!e || !n || mode >= e->cfg.n_modes || group >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
+    ON_ENGINE_DEVICE(e);
+    int rc = fetch_chains(e);
+    if (rc) return rc;
+    const uint32_t c = mode * e->cfg.n_groups + group;
+    const uint32_t len = e->h_chains[c].len;
+    const uint32_t k = len < *n ? len : *n;
+    *n = len;
+    if (slots && k) {
+        // the queue lives in q_slot[chain][0 .. len) in order, head at 0
+        HIPCHK(e, hipMemcpyAsync(slots, e->d_q_slot + (size_t)c * e->cfg.capacity, (size_t)k * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    return MM_OK;
+}
+
 extern "C" int mm_lobby_state(mm_engine* e, uint32_t mode, uint32_t group, uint32_t* n, uint32_t* slots,
                               uint8_t* teams)
 {

@@ -24,6 +24,7 @@ defmodule Matchmaking.Search.Engine do
   def cancel(_engine, _slots), do: :erlang.nif_error(:nif_not_loaded)
   def tick(_engine, _mode), do: :erlang.nif_error(:nif_not_loaded)
   def queue_depth(_engine, _mode), do: :erlang.nif_error(:nif_not_loaded)
+  def queue_slots(_engine, _mode, _group), do: :erlang.nif_error(:nif_not_loaded)
   def lobby_state(_engine, _mode, _group), do: :erlang.nif_error(:nif_not_loaded)
   def snapshot(_engine), do: :erlang.nif_error(:nif_not_loaded)
   def restore(_engine, _blob), do: :erlang.nif_error(:nif_not_loaded)

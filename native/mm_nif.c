@@ -186,6 +186,21 @@ static ERL_NIF_TERM nif_queue_depth(ErlNifEnv* env, int argc, const ERL_NIF_TERM
     return rc ? err(env, rc) : enif_make_tuple2(env, A_OK, out);
 }
 
+/* queue_slots(engine, mode, group) -> {:ok, <<slot::little-32, ...>>}   head first: the order the
+ * broker would deliver in, requeues at the tail (worker.ex:239-248, requeue/worker.ex:51-54) */
+static ERL_NIF_TERM nif_queue_slots(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+    (void)argc;
+    nif_engine* r; unsigned mode, group; uint32_t n = 0; ERL_NIF_TERM out;
+    if (!get_engine(env, argv[0], &r) || !enif_get_uint(env, argv[1], &mode) || !enif_get_uint(env, argv[2], &group))
+        return enif_make_badarg(env);
+    int rc = mm_queue_slots(r->e, mode, group, &n, NULL);   /* length query */
+    if (rc) return err(env, rc);
+    uint32_t cap = n;
+    uint32_t* d = (uint32_t*)enif_make_new_binary(env, (size_t)cap * 4, &out);
+    rc = mm_queue_slots(r->e, mode, group, &n, d);          /* one owner: the queue cannot have moved */
+    return rc ? err(env, rc) : enif_make_tuple2(env, A_OK, out);
+}
+
 /* lobby_state(engine, mode, group) -> {:ok, slots, teams}          lobby_state.ex:61-104 */
 static ERL_NIF_TERM nif_lobby_state(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
     (void)argc;
@@ -321,6 +336,7 @@ static ErlNifFunc funcs[] = {
     {"cancel", 2, nif_cancel, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"tick", 2, nif_tick, ERL_NIF_DIRTY_JOB_CPU_BOUND},          /* blocks on the stream until quiescence */
     {"queue_depth", 2, nif_queue_depth, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"queue_slots", 3, nif_queue_slots, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"lobby_state", 3, nif_lobby_state, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"snapshot", 1, nif_snapshot, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"restore", 2, nif_restore, ERL_NIF_DIRTY_JOB_IO_BOUND},

@@ -72,9 +72,14 @@ def assert_same_tick(a, b, tag="", score_tol=1e-6):
 
 
 def assert_same_state(ea, eb, cfg, tag=""):
+    """Queue depth, queue ORDER (requeue ordering, worker.ex:239-248 -> requeue/worker.ex:51-54: the
+    survivors of a tick in the order the broker would deliver them next) and the stored lobby."""
     for mode in range(cfg.n_modes):
         assert np.array_equal(ea.queue_depth(mode), eb.queue_depth(mode)), (tag, "depth", mode)
         for g in range(cfg.n_groups):
+            qa, qb = ea.queue_slots(mode, g), eb.queue_slots(mode, g)
+            assert np.array_equal(qa, qb), (tag, "queue order", mode, g,
+                                            int(np.argmax(qa != qb)) if qa.shape == qb.shape else (qa.shape, qb.shape))
             sa, ta = ea.lobby_state(mode, g)
             sb, tb = eb.lobby_state(mode, g)
             assert np.array_equal(sa, sb) and np.array_equal(ta, tb), (tag, "lobby", mode, g, sa, sb)

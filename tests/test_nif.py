@@ -35,7 +35,7 @@ def test_function_table_is_what_the_elixir_module_declares(beam):
     assert beam.module == "Elixir.Matchmaking.Search.Engine"
     assert set(beam.table) == {("default_config", 0), ("find_rating_group", 2), ("create", 1), ("close", 1),
                                ("reset", 1), ("enqueue", 4), ("cancel", 2), ("tick", 2), ("queue_depth", 2),
-                               ("lobby_state", 3), ("snapshot", 1), ("restore", 2), ("decode", 7),
+                               ("queue_slots", 3), ("lobby_state", 3), ("snapshot", 1), ("restore", 2), ("decode", 7),
                                ("encode_lobby", 4)}
     # whatever can block on the device is a dirty NIF; tick blocks on the stream -> CPU bound
     assert beam.table[("tick", 2)][1] == DIRTY_CPU
@@ -90,6 +90,8 @@ def scenario(beam, n=6000, seed=5):
                 ok, depth = beam.call("queue_depth", eng, mode)
                 assert ok == "ok" and np.array_equal(u32(depth), cpu.queue_depth(mode))
                 for grp in range(cfg.n_groups):
+                    ok, qs = beam.call("queue_slots", eng, mode, grp)
+                    assert ok == "ok" and np.array_equal(u32(qs), cpu.queue_slots(mode, grp))
                     ok, ls, lt = beam.call("lobby_state", eng, mode, grp)
                     ws, wt = cpu.lobby_state(mode, grp)
                     assert ok == "ok" and np.array_equal(u32(ls), ws) and np.array_equal(np.frombuffer(lt, "u1"), wt)
