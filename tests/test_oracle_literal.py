@@ -158,3 +158,40 @@ def test_literal_rating_group_matches_golden():
         g = find_rating_group_by_rating(r)
         assert REFERENCE_RATING_GROUPS.index(g) == want
     assert find_rating_group_by_rating(None)[2] == "diamond"
+
+
+def test_per_chain_tick_boundary_is_the_only_departure_from_the_shared_queue():
+    """The golden case `tick_ends_per_chain_while_another_mode_of_the_group_progresses` on the
+    literal restatement, both ways: one literal stage per mode (Mode R's per-chain tick) leaves B
+    queued and the lobby empty, exactly as the golden case says; ONE literal queue for both modes
+    (worker.ex:308-321 read literally: the group's rotation goes on while mode 1 seats players)
+    seats B one rotation later inside the same tick.  The next tick brings both to the same state."""
+    from helpers import load_golden, players_to_arrays
+    case = [c for c in load_golden()["cases"] if c["name"].startswith("tick_ends_per_chain")][0]
+    cfg = make_config(case["modes"], capacity=64)
+
+    def run(shared):
+        stages = [literal_stage(cfg)] if shared else [literal_stage(cfg) for _ in range(cfg.n_modes)]
+        next_slot, lobbies = 0, []
+        for step in case["steps"]:
+            if step["op"] == "enqueue":
+                r, c = players_to_arrays(step["players"])
+                for rr, cc in zip(r, c):
+                    stages[0 if shared else int(cc) & 0xF].deliver(to_payload(next_slot, rr, cc))
+                    next_slot += 1
+            elif step["op"] == "cancel":
+                for s in step["slots"]:
+                    for st in stages:
+                        st.cancel(s)
+            else:
+                st = stages[0 if shared else step["mode"]]
+                st.run_group_to_quiescence("bronze")
+                rec = [r for r in st.lobbies.tables["bronze"] if r[2] == "mode%d" % step["mode"]]
+                lobbies.append([p["id"] for r in rec for t in sorted(r[1]) for p in r[1][t]])
+        return lobbies
+
+    per_chain, shared = run(False), run(True)
+    want = [s["expect"]["lobby"]["0"]["slots"] for s in case["steps"] if s["op"] == "tick"]
+    assert per_chain == want == [[0], [], [], [1]]
+    assert shared == [[0], [1], [], [1]]           # B meets the filtered lobby within tick 2 (3rd entry: mode 1's lobby)
+    assert per_chain[-1] == shared[-1]             # deferred to the tick boundary, never lost
