@@ -13,7 +13,11 @@
  *   - plain C types only, no torch/HIP types in signatures;
  *   - returns 0 (MM_OK) or a negative mm_status; never throws, aborts or exits
  *     (a NIF crash would take the whole BEAM down — contrast the per-worker
- *     `restart: :transient` isolation at lib/application.ex:8-14);
+ *     `restart: :transient` isolation at lib/application.ex:8-14): every entry point that can
+ *     allocate catches at the boundary (MM_ERR_OOM for std::bad_alloc, MM_ERR_INTERNAL otherwise);
+ *   - after MM_ERR_HIP / MM_ERR_INTERNAL / MM_ERR_OOM from mm_tick the device work already queued has
+ *     finished (the stream is synchronised before the error is returned) but queues and lobbies are
+ *     in a mid-tick state: call mm_reset or mm_restore before using the engine again;
  *   - one owner per engine, no internal locking: calls on one engine never overlap (one
  *     GenServer owns one engine, as one Search.Worker owns one channel:
  *     lib/search/worker.ex:220-237).  The owner need not stay on one OS thread — a dirty NIF
@@ -186,9 +190,9 @@ int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const uint32_t* 
 /* Same, with rating/cons already resident in device memory (the benchmark path, and a
  * GPU-side codec's hand-off).  Slots are first_slot + i (mod capacity): this entry point needs
  * that whole range free and returns MM_ERR_FULL otherwise (it does not step over waiting
- * players — a service with long-waiting players ingests through mm_enqueue).  The host
- * never sees which players of a device-resident batch were rejected (st->rejected counts
- * them), so their slots stay reserved until mm_reset. */
+ * players — a service with long-waiting players ingests through mm_enqueue).  A rejected
+ * player (mode not configured, role not seatable; st->rejected counts them) leaves its slot of
+ * the range FREE: it is in no queue, mm_cancel ignores it, and a later batch takes the slot. */
 int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rating,
                       const uint32_t* d_cons, uint32_t* first_slot, mm_enqueue_stats* st);
 

@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "../../include/mm_engine.h"
+#include <mm_gfx950.h>
 
 // ------------------------------------------------------------------------------------
 // device-side structures
@@ -1152,129 +1153,141 @@ static int engine_reset_device(mm_engine* e)
 
 extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
 {
-    if (!cfg || !out) return MM_ERR_INVALID_ARG;
-    *out = NULL;
-    int rc = cfg_validate(cfg);
-    if (rc) return rc;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
-        return MM_ERR_NO_DEVICE;
-    mm_engine* e = new (std::nothrow) mm_engine();
-    if (!e) return MM_ERR_OOM;
-    e->cfg = *cfg;
-    e->n_chains = cfg->n_modes * cfg->n_groups;
-    e->last_hip = 0;
-    e->next_slot = 0;
-    e->cancel_pending = 0;
-    e->r_n = 0;
-    e->r_L = 2;
-    e->in_cap = 0;
-    e->wave_hist_rows = 0;
-    e->live_upper = 0;
-    {
-        const char* fg = getenv("MM_FORCE_GENERIC");
-        e->force_generic = fg && fg[0] == '1';
-        const char* pd = getenv("MM_PAIR_DEBUG");
-        e->pair_debug = pd && pd[0] == '1';
-        const char* pt = getenv("MM_PAIR_TUNE");
-        e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
-        const char* pf = getenv("MM_PAIR_FUSED");
-        e->pair_fused = !(pf && pf[0] == '0');
-        e->round_ctr = 0;
-        const char* pb = getenv("MM_PAIR_BATCH");
-        e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 32u;
-        if (e->pair_batch < 1u) e->pair_batch = 1u;
-        const char* tb = getenv("MM_TEAM_BATCH");
-        e->team_batch = tb ? (uint32_t)strtoul(tb, NULL, 0) : 16u;
-        if (e->team_batch < 1u) e->team_batch = 1u;
-        const char* tcap = getenv("MM_TEAM_CAP");
-        e->team_cap = tcap ? (uint32_t)strtoul(tcap, NULL, 0) : TT_SCAN_CAP;
-        if (e->team_cap < 1u) e->team_cap = 1u;
-    }
-    const size_t cap = cfg->capacity;
-#define CREATE_CHK(call)                                                 \
-    do {                                                                 \
-        hipError_t _rc = (call);                                         \
-        if (_rc != hipSuccess) {                                         \
-            int code = _rc == hipErrorOutOfMemory ? MM_ERR_OOM : MM_ERR_HIP; \
-            mm_engine_destroy(e);                                        \
-            return code;                                                 \
-        }                                                                \
-    } while (0)
-    DeviceScope dev_scope(cfg->device);        // the caller's device is put back when create returns
-    if (!dev_scope.ok) {
-        mm_engine_destroy(e);
-        return MM_ERR_HIP;
-    }
-    CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 4; ++i) CREATE_CHK(hipEventCreate(&e->ev[i]));
-    CREATE_CHK(hipMalloc((void**)&e->d_q_rating, e->n_chains * cap * sizeof(int32_t)));
-    CREATE_CHK(hipMalloc((void**)&e->d_q_cons, e->n_chains * cap * sizeof(uint32_t)));
-    CREATE_CHK(hipMalloc((void**)&e->d_q_slot, e->n_chains * cap * sizeof(uint32_t)));
-    CREATE_CHK(hipMalloc((void**)&e->d_chains, e->n_chains * sizeof(ChainDev)));
-    CREATE_CHK(hipMalloc((void**)&e->d_state, cap));
-    CREATE_CHK(hipMalloc((void**)&e->d_released, (cap + 64) * sizeof(uint32_t)));
-    CREATE_CHK(hipMalloc((void**)&e->d_counters, 2 * sizeof(uint32_t)));
-    // emission logs: a group can emit at most (cap + lobby) / 2 lobbies of >= 2 players
-    e->out_slot_stride = (uint32_t)(cap + 64);
-    e->out_rec_stride = (uint32_t)(cap / 2 + 16);
-    CREATE_CHK(hipMalloc((void**)&e->d_out_slots, (size_t)cfg->n_groups * e->out_slot_stride * sizeof(uint32_t)));
-    CREATE_CHK(hipMalloc((void**)&e->d_out_score, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(float)));
-    CREATE_CHK(hipMalloc((void**)&e->d_out_pass, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(uint32_t)));
-    {
-        e->pk_stride = (uint32_t)((cap + 63) & ~(size_t)63);
-        const size_t gc = (size_t)cfg->n_groups * e->pk_stride;
-        e->pk_bits_stride = (uint32_t)(cap / 32 + 4);
-        CREATE_CHK(hipMalloc((void**)&e->d_pchains, cfg->n_groups * sizeof(PairChain)));
-        e->pk_max_tiles = (uint32_t)(cap / PK_T + 2);
-        for (int b = 0; b < 2; ++b) {
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_key[b], (gc + 64) * sizeof(uint32_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_oidx[b], gc * sizeof(uint32_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_nx16[b], (gc + 64) * sizeof(uint16_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_bits[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
+    try {
+        if (!cfg || !out) return MM_ERR_INVALID_ARG;
+        *out = NULL;
+        int rc = cfg_validate(cfg);
+        if (rc) return rc;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+            return MM_ERR_NO_DEVICE;
+        mm_engine* e = new (std::nothrow) mm_engine();
+        if (!e) return MM_ERR_OOM;
+        e->cfg = *cfg;
+        e->n_chains = cfg->n_modes * cfg->n_groups;
+        e->last_hip = 0;
+        e->next_slot = 0;
+        e->cancel_pending = 0;
+        e->r_n = 0;
+        e->r_L = 2;
+        e->in_cap = 0;
+        e->wave_hist_rows = 0;
+        e->live_upper = 0;
+        {
+            const char* fg = getenv("MM_FORCE_GENERIC");
+            e->force_generic = fg && fg[0] == '1';
+            const char* pd = getenv("MM_PAIR_DEBUG");
+            e->pair_debug = pd && pd[0] == '1';
+            const char* pt = getenv("MM_PAIR_TUNE");
+            e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
+            const char* pf = getenv("MM_PAIR_FUSED");
+            e->pair_fused = !(pf && pf[0] == '0');
+            e->round_ctr = 0;
+            const char* pb = getenv("MM_PAIR_BATCH");
+            e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 32u;
+            if (e->pair_batch < 1u) e->pair_batch = 1u;
+            const char* tb = getenv("MM_TEAM_BATCH");
+            e->team_batch = tb ? (uint32_t)strtoul(tb, NULL, 0) : 16u;
+            if (e->team_batch < 1u) e->team_batch = 1u;
+            const char* tcap = getenv("MM_TEAM_CAP");
+            e->team_cap = tcap ? (uint32_t)strtoul(tcap, NULL, 0) : TT_SCAN_CAP;
+            if (e->team_cap < 1u) e->team_cap = 1u;
         }
-        CREATE_CHK(hipMalloc((void**)&e->d_pk_scratch, gc * sizeof(uint32_t)));
-        CREATE_CHK(hipMalloc((void**)&e->d_pk_g16, (gc + 64) * sizeof(uint16_t)));
-        CREATE_CHK(hipMalloc((void**)&e->d_pk_rec1, gc * sizeof(uint32_t)));
-        for (int b = 0; b < 2; ++b) {
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_exa[b], (gc + 64) * sizeof(uint16_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_bitsp[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_headp[b], (size_t)cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
+        const size_t cap = cfg->capacity;
+    #define CREATE_CHK(call)                                                 \
+        do {                                                                 \
+            hipError_t _rc = (call);                                         \
+            if (_rc != hipSuccess) {                                         \
+                int code = _rc == hipErrorOutOfMemory ? MM_ERR_OOM : MM_ERR_HIP; \
+                mm_engine_destroy(e);                                        \
+                return code;                                                 \
+            }                                                                \
+        } while (0)
+        DeviceScope dev_scope(cfg->device);        // the caller's device is put back when create returns
+        if (!dev_scope.ok) {
+            mm_engine_destroy(e);
+            return MM_ERR_HIP;
         }
-        CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
-        CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
-        CREATE_CHK(hipHostMalloc((void**)&e->h_pchains, cfg->n_groups * sizeof(PairChain), hipHostMallocDefault));
-        // a tick emits at most (cap + lobby) / 2 lobbies per group, cap + lobbies-in-progress players overall
-        CREATE_CHK(hipHostMalloc((void**)&e->h_rslots, (cap + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
-        CREATE_CHK(hipHostMalloc((void**)&e->h_rscore, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(float), hipHostMallocDefault));
-        CREATE_CHK(hipHostMalloc((void**)&e->h_rpass, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
-        CREATE_CHK(hipMemsetAsync(e->d_pchains, 0, cfg->n_groups * sizeof(PairChain), e->stream));
-        e->tk_chunk_stride = (uint32_t)(e->pk_stride / TT_CH + 2);
-        CREATE_CHK(hipMalloc((void**)&e->d_tchains, cfg->n_groups * sizeof(TeamChain)));
-        CREATE_CHK(hipMalloc((void**)&e->d_tk_chunk, (size_t)cfg->n_groups * MM_MAX_ROLES * e->tk_chunk_stride * sizeof(uint32_t)));
-        CREATE_CHK(hipHostMalloc((void**)&e->h_tchains, cfg->n_groups * sizeof(TeamChain), hipHostMallocDefault));
-        CREATE_CHK(hipMemsetAsync(e->d_tchains, 0, cfg->n_groups * sizeof(TeamChain), e->stream));
+        CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) CREATE_CHK(hipEventCreate(&e->ev[i]));
+        CREATE_CHK(hipMalloc((void**)&e->d_q_rating, e->n_chains * cap * sizeof(int32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_q_cons, e->n_chains * cap * sizeof(uint32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_q_slot, e->n_chains * cap * sizeof(uint32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_chains, e->n_chains * sizeof(ChainDev)));
+        CREATE_CHK(hipMalloc((void**)&e->d_state, cap));
+        CREATE_CHK(hipMalloc((void**)&e->d_released, (cap + 64) * sizeof(uint32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_counters, 2 * sizeof(uint32_t)));
+        // emission logs: a group can emit at most (cap + lobby) / 2 lobbies of >= 2 players
+        e->out_slot_stride = (uint32_t)(cap + 64);
+        e->out_rec_stride = (uint32_t)(cap / 2 + 16);
+        CREATE_CHK(hipMalloc((void**)&e->d_out_slots, (size_t)cfg->n_groups * e->out_slot_stride * sizeof(uint32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_out_score, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(float)));
+        CREATE_CHK(hipMalloc((void**)&e->d_out_pass, (size_t)cfg->n_groups * e->out_rec_stride * sizeof(uint32_t)));
+        {
+            e->pk_stride = (uint32_t)((cap + 63) & ~(size_t)63);
+            const size_t gc = (size_t)cfg->n_groups * e->pk_stride;
+            e->pk_bits_stride = (uint32_t)(cap / 32 + 4);
+            CREATE_CHK(hipMalloc((void**)&e->d_pchains, cfg->n_groups * sizeof(PairChain)));
+            e->pk_max_tiles = (uint32_t)(cap / PK_T + 2);
+            for (int b = 0; b < 2; ++b) {
+                CREATE_CHK(hipMalloc((void**)&e->d_pk_key[b], (gc + 64) * sizeof(uint32_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_pk_oidx[b], gc * sizeof(uint32_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_pk_nx16[b], (gc + 64) * sizeof(uint16_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_pk_bits[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
+            }
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_scratch, gc * sizeof(uint32_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_g16, (gc + 64) * sizeof(uint16_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_rec1, gc * sizeof(uint32_t)));
+            for (int b = 0; b < 2; ++b) {
+                CREATE_CHK(hipMalloc((void**)&e->d_pk_exa[b], (gc + 64) * sizeof(uint16_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_pk_bitsp[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_pk_headp[b], (size_t)cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
+            }
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
+            CREATE_CHK(hipHostMalloc((void**)&e->h_pchains, cfg->n_groups * sizeof(PairChain), hipHostMallocDefault));
+            // a tick emits at most (cap + lobby) / 2 lobbies per group, cap + lobbies-in-progress players overall
+            CREATE_CHK(hipHostMalloc((void**)&e->h_rslots, (cap + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
+            CREATE_CHK(hipHostMalloc((void**)&e->h_rscore, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(float), hipHostMallocDefault));
+            CREATE_CHK(hipHostMalloc((void**)&e->h_rpass, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
+            CREATE_CHK(hipMemsetAsync(e->d_pchains, 0, cfg->n_groups * sizeof(PairChain), e->stream));
+            e->tk_chunk_stride = (uint32_t)(e->pk_stride / TT_CH + 2);
+            CREATE_CHK(hipMalloc((void**)&e->d_tchains, cfg->n_groups * sizeof(TeamChain)));
+            CREATE_CHK(hipMalloc((void**)&e->d_tk_chunk, (size_t)cfg->n_groups * MM_MAX_ROLES * e->tk_chunk_stride * sizeof(uint32_t)));
+            CREATE_CHK(hipHostMalloc((void**)&e->h_tchains, cfg->n_groups * sizeof(TeamChain), hipHostMallocDefault));
+            CREATE_CHK(hipMemsetAsync(e->d_tchains, 0, cfg->n_groups * sizeof(TeamChain), e->stream));
+        }
+        CREATE_CHK(hipHostMalloc((void**)&e->h_chains, e->n_chains * sizeof(ChainDev), hipHostMallocDefault));
+        CREATE_CHK(hipHostMalloc((void**)&e->h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault));
+    #undef CREATE_CHK
+        e->h_state.assign(cap, MM_ST_FREE);
+        rc = engine_reset_device(e);
+        if (rc) { mm_engine_destroy(e); return rc; }
+        *out = e;
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
     }
-    CREATE_CHK(hipHostMalloc((void**)&e->h_chains, e->n_chains * sizeof(ChainDev), hipHostMallocDefault));
-    CREATE_CHK(hipHostMalloc((void**)&e->h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault));
-#undef CREATE_CHK
-    e->h_state.assign(cap, MM_ST_FREE);
-    rc = engine_reset_device(e);
-    if (rc) { mm_engine_destroy(e); return rc; }
-    *out = e;
-    return MM_OK;
 }
 
 extern "C" int mm_reset(mm_engine* e)
 {
-    if (!e) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    std::fill(e->h_state.begin(), e->h_state.end(), (uint8_t)MM_ST_FREE);
-    e->next_slot = 0;
-    e->cancel_pending = 0;
-    e->r_n = 0;
-    e->live_upper = 0;
-    return engine_reset_device(e);
+    try {
+        if (!e) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        std::fill(e->h_state.begin(), e->h_state.end(), (uint8_t)MM_ST_FREE);
+        e->next_slot = 0;
+        e->cancel_pending = 0;
+        e->r_n = 0;
+        e->live_upper = 0;
+        return engine_reset_device(e);
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
+    }
 }
 
 static int ensure_staging(mm_engine* e, size_t n)
@@ -1370,100 +1383,129 @@ static int pick_free_slots(const mm_engine* e, uint32_t n, std::vector<uint32_t>
 extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const uint32_t* cons,
                           const uint8_t* group, uint32_t* out_slot, mm_enqueue_stats* st)
 {
-    if (!e || (n && (!rating || !cons))) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    const double t0 = host_now_ms();
-    if (st) memset(st, 0, sizeof(*st));
-    if (n == 0) return MM_OK;
-    std::vector<uint32_t> sel;
-    bool contiguous = false;
-    if (!pick_free_slots(e, n, sel, &contiguous)) return MM_ERR_FULL;
-    if (group)
+    try {
+        if (!e || (n && (!rating || !cons))) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        const double t0 = host_now_ms();
+        if (st) memset(st, 0, sizeof(*st));
+        if (n == 0) return MM_OK;
+        std::vector<uint32_t> sel;
+        bool contiguous = false;
+        if (!pick_free_slots(e, n, sel, &contiguous)) return MM_ERR_FULL;
+        if (group)
+            for (uint32_t i = 0; i < n; ++i)
+                if (group[i] >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
+        int rc = ensure_staging(e, n);
+        if (rc) return rc;
+        if (!contiguous)
+            HIPCHK(e, hipMemcpyAsync(e->d_in_sel, sel.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_in_rating, rating, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_in_cons, cons, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        if (group) HIPCHK(e, hipMemcpyAsync(e->d_in_group, group, n, hipMemcpyHostToDevice, e->stream));
+        uint32_t rejected = 0;
+        float bms = 0.f;
+        rc = enqueue_device_impl(e, n, e->d_in_rating, e->d_in_cons, group ? e->d_in_group : NULL,
+                                 contiguous ? NULL : e->d_in_sel, e->d_in_slot, &rejected, &bms);   // syncs: `sel` outlives the copy
+        if (rc) return rc;
+        std::vector<uint32_t> tmp;
+        uint32_t* slots = out_slot;
+        if (!slots) { tmp.resize(n); slots = tmp.data(); }
+        HIPCHK(e, hipMemcpy(slots, e->d_in_slot, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n; ++i)
-            if (group[i] >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
-    int rc = ensure_staging(e, n);
-    if (rc) return rc;
-    if (!contiguous)
-        HIPCHK(e, hipMemcpyAsync(e->d_in_sel, sel.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->d_in_rating, rating, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->d_in_cons, cons, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    if (group) HIPCHK(e, hipMemcpyAsync(e->d_in_group, group, n, hipMemcpyHostToDevice, e->stream));
-    uint32_t rejected = 0;
-    float bms = 0.f;
-    rc = enqueue_device_impl(e, n, e->d_in_rating, e->d_in_cons, group ? e->d_in_group : NULL,
-                             contiguous ? NULL : e->d_in_sel, e->d_in_slot, &rejected, &bms);   // syncs: `sel` outlives the copy
-    if (rc) return rc;
-    std::vector<uint32_t> tmp;
-    uint32_t* slots = out_slot;
-    if (!slots) { tmp.resize(n); slots = tmp.data(); }
-    HIPCHK(e, hipMemcpy(slots, e->d_in_slot, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n; ++i)
-        if (slots[i] != MM_NO_SLOT) e->h_state[slots[i]] = MM_ST_LIVE;
-    e->next_slot = contiguous ? (uint32_t)(((unsigned long long)e->next_slot + n) % e->cfg.capacity)
-                              : (sel[n - 1] + 1u) % e->cfg.capacity;
-    e->live_upper += n - rejected;
-    if (st) {
-        st->accepted = n - rejected;
-        st->rejected = rejected;
-        st->bucket_ms = bms;
-        st->total_ms = (float)(host_now_ms() - t0);
+            if (slots[i] != MM_NO_SLOT) e->h_state[slots[i]] = MM_ST_LIVE;
+        e->next_slot = contiguous ? (uint32_t)(((unsigned long long)e->next_slot + n) % e->cfg.capacity)
+                                  : (sel[n - 1] + 1u) % e->cfg.capacity;
+        e->live_upper += n - rejected;
+        if (st) {
+            st->accepted = n - rejected;
+            st->rejected = rejected;
+            st->bucket_ms = bms;
+            st->total_ms = (float)(host_now_ms() - t0);
+        }
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
     }
-    return MM_OK;
 }
 
 extern "C" int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rating, const uint32_t* d_cons,
                                  uint32_t* first_slot, mm_enqueue_stats* st)
 {
-    if (!e || (n && (!d_rating || !d_cons))) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    const double t0 = host_now_ms();
-    if (st) memset(st, 0, sizeof(*st));
-    if (first_slot) *first_slot = e->next_slot;
-    if (n == 0) return MM_OK;
-    if (!ring_range_free(e, n)) return MM_ERR_FULL;
-    uint32_t rejected = 0;
-    float bms = 0.f;
-    int rc = enqueue_device_impl(e, n, d_rating, d_cons, NULL, NULL, NULL, &rejected, &bms);
-    if (rc) return rc;
-    // the host cannot see which players were rejected: the whole range stays reserved
-    const uint32_t cap = e->cfg.capacity;
-    const uint32_t a = e->next_slot, n1 = n < cap - a ? n : cap - a;
-    memset(&e->h_state[a], MM_ST_LIVE, n1);
-    if (n > n1) memset(&e->h_state[0], MM_ST_LIVE, n - n1);
-    e->next_slot = (uint32_t)(((unsigned long long)a + n) % cap);
-    e->live_upper += n - rejected;
-    if (st) {
-        st->accepted = n - rejected;
-        st->rejected = rejected;
-        st->bucket_ms = bms;
-        st->total_ms = (float)(host_now_ms() - t0);
+    try {
+        if (!e || (n && (!d_rating || !d_cons))) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        const double t0 = host_now_ms();
+        if (st) memset(st, 0, sizeof(*st));
+        if (first_slot) *first_slot = e->next_slot;
+        if (n == 0) return MM_OK;
+        if (!ring_range_free(e, n)) return MM_ERR_FULL;
+        uint32_t rejected = 0;
+        float bms = 0.f;
+        int rc = ensure_staging(e, n);                       // the slot column (d_in_slot) of the batch
+        if (rc) return rc;
+        rc = enqueue_device_impl(e, n, d_rating, d_cons, NULL, NULL, e->d_in_slot, &rejected, &bms);
+        if (rc) return rc;
+        const uint32_t cap = e->cfg.capacity;
+        const uint32_t a = e->next_slot, n1 = n < cap - a ? n : cap - a;
+        if (rejected == 0u) {
+            memset(&e->h_state[a], MM_ST_LIVE, n1);
+            if (n > n1) memset(&e->h_state[0], MM_ST_LIVE, n - n1);
+        } else {
+            // some players were refused on the device (mode not configured, role not seatable): only the
+            // accepted ones hold their slot; a refused player's slot stays FREE (it is in no queue and no
+            // lobby, nothing would ever release it)
+            std::vector<uint32_t> got(n);
+            HIPCHK(e, hipMemcpy(got.data(), e->d_in_slot, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n; ++i)
+                if (got[i] != MM_NO_SLOT) e->h_state[got[i]] = MM_ST_LIVE;
+        }
+        e->next_slot = (uint32_t)(((unsigned long long)a + n) % cap);
+        e->live_upper += n - rejected;
+        if (st) {
+            st->accepted = n - rejected;
+            st->rejected = rejected;
+            st->bucket_ms = bms;
+            st->total_ms = (float)(host_now_ms() - t0);
+        }
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
     }
-    return MM_OK;
 }
 
 extern "C" int mm_cancel(mm_engine* e, uint32_t n, const uint32_t* slot)
 {
-    if (!e || (n && !slot)) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    std::vector<uint32_t> live;
-    live.reserve(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        if (slot[i] >= e->cfg.capacity) continue;
-        if (e->h_state[slot[i]] == MM_ST_LIVE) {
-            e->h_state[slot[i]] = MM_ST_CANCELLED;
-            live.push_back(slot[i]);
+    try {
+        if (!e || (n && !slot)) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        std::vector<uint32_t> live;
+        live.reserve(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (slot[i] >= e->cfg.capacity) continue;
+            if (e->h_state[slot[i]] == MM_ST_LIVE) {
+                e->h_state[slot[i]] = MM_ST_CANCELLED;
+                live.push_back(slot[i]);
+            }
         }
+        if (live.empty()) return MM_OK;
+        int rc = ensure_staging(e, live.size());
+        if (rc) return rc;
+        const uint32_t k = (uint32_t)live.size();
+        HIPCHK(e, hipMemcpyAsync(e->d_in_slot, live.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(k_cancel, dim3((k + 255) / 256), dim3(256), 0, e->stream, k, e->d_in_slot, e->d_state);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->stream));   // `live` must outlive the copy
+        e->cancel_pending += k;
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
     }
-    if (live.empty()) return MM_OK;
-    int rc = ensure_staging(e, live.size());
-    if (rc) return rc;
-    const uint32_t k = (uint32_t)live.size();
-    HIPCHK(e, hipMemcpyAsync(e->d_in_slot, live.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_cancel, dim3((k + 255) / 256), dim3(256), 0, e->stream, k, e->d_in_slot, e->d_state);
-    HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->stream));   // `live` must outlive the copy
-    e->cancel_pending += k;
-    return MM_OK;
 }
 
 // The pair path (mm_pair.inc) for every chain of `mode` it is eligible for; the others are
@@ -1671,10 +1713,34 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     return MM_OK;
 }
 
+static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats);
+
+// The exported tick: nothing may unwind into the caller (a NIF frame), and a tick that fails half
+// way must not leave kernels in flight behind the error code.
 extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats)
 {
     if (!e || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
     ON_ENGINE_DEVICE(e);
+    int rc;
+    try {
+        rc = tick_impl(e, mode, n_matches, stats);
+    } catch (const std::bad_alloc&) {
+        rc = MM_ERR_OOM;
+    } catch (...) {
+        rc = MM_ERR_INTERNAL;
+    }
+    if (rc != MM_OK) {
+        // whatever was enqueued on the stream finishes before the caller sees the error; the queues
+        // and lobbies are then in an unspecified (mid-tick) state: mm_reset or mm_restore before
+        // the engine is used again (mm_engine.h)
+        (void)hipStreamSynchronize(e->stream);
+        e->r_n = 0;
+    }
+    return rc;
+}
+
+static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats)
+{
     const double t0 = host_now_ms();
     const mm_config& cfg = e->cfg;
     const uint32_t G = cfg.n_groups;
@@ -1815,14 +1881,20 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
 extern "C" int mm_matches(mm_engine* e, uint32_t first, uint32_t count, uint32_t* slots, float* score,
                           uint32_t* group, uint32_t* pass)
 {
-    if (!e) return MM_ERR_INVALID_ARG;
-    if (first > e->r_n || count > e->r_n - first) return MM_ERR_RANGE;
-    if (count == 0) return MM_OK;
-    if (slots) memcpy(slots, &e->h_rslots[(size_t)first * e->r_L], (size_t)count * e->r_L * sizeof(uint32_t));
-    if (score) memcpy(score, &e->h_rscore[first], count * sizeof(float));
-    if (group) memcpy(group, &e->r_group[first], count * sizeof(uint32_t));
-    if (pass) memcpy(pass, &e->h_rpass[first], count * sizeof(uint32_t));
-    return MM_OK;
+    try {
+        if (!e) return MM_ERR_INVALID_ARG;
+        if (first > e->r_n || count > e->r_n - first) return MM_ERR_RANGE;
+        if (count == 0) return MM_OK;
+        if (slots) memcpy(slots, &e->h_rslots[(size_t)first * e->r_L], (size_t)count * e->r_L * sizeof(uint32_t));
+        if (score) memcpy(score, &e->h_rscore[first], count * sizeof(float));
+        if (group) memcpy(group, &e->r_group[first], count * sizeof(uint32_t));
+        if (pass) memcpy(pass, &e->h_rpass[first], count * sizeof(uint32_t));
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
+    }
 }
 
 static int fetch_chains(mm_engine* e)
@@ -1834,50 +1906,68 @@ static int fetch_chains(mm_engine* e)
 
 extern "C" int mm_queue_depth(mm_engine* e, uint32_t mode, uint32_t* per_group)
 {
-    if (!e || !per_group || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    int rc = fetch_chains(e);
-    if (rc) return rc;
-    for (uint32_t g = 0; g < e->cfg.n_groups; ++g) per_group[g] = e->h_chains[mode * e->cfg.n_groups + g].len;
-    return MM_OK;
+    try {
+        if (!e || !per_group || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        int rc = fetch_chains(e);
+        if (rc) return rc;
+        for (uint32_t g = 0; g < e->cfg.n_groups; ++g) per_group[g] = e->h_chains[mode * e->cfg.n_groups + g].len;
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
+    }
 }
 
 extern "C" int mm_queue_slots(mm_engine* e, uint32_t mode, uint32_t group, uint32_t* n, uint32_t* slots)
 {
-    if (!e || !n || mode >= e->cfg.n_modes || group >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    int rc = fetch_chains(e);
-    if (rc) return rc;
-    const uint32_t c = mode * e->cfg.n_groups + group;
-    const uint32_t len = e->h_chains[c].len;
-    const uint32_t k = len < *n ? len : *n;
-    *n = len;
-    if (slots && k) {
-        // the queue lives in q_slot[chain][0 .. len) in order, head at 0
-        HIPCHK(e, hipMemcpyAsync(slots, e->d_q_slot + (size_t)c * e->cfg.capacity, (size_t)k * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipStreamSynchronize(e->stream));
+    try {
+        if (!e || !n || mode >= e->cfg.n_modes || group >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        int rc = fetch_chains(e);
+        if (rc) return rc;
+        const uint32_t c = mode * e->cfg.n_groups + group;
+        const uint32_t len = e->h_chains[c].len;
+        const uint32_t k = len < *n ? len : *n;
+        *n = len;
+        if (slots && k) {
+            // the queue lives in q_slot[chain][0 .. len) in order, head at 0
+            HIPCHK(e, hipMemcpyAsync(slots, e->d_q_slot + (size_t)c * e->cfg.capacity, (size_t)k * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+        }
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
     }
-    return MM_OK;
 }
 
 extern "C" int mm_lobby_state(mm_engine* e, uint32_t mode, uint32_t group, uint32_t* n, uint32_t* slots,
                               uint8_t* teams)
 {
-    if (!e || !n || mode >= e->cfg.n_modes || group >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    int rc = fetch_chains(e);
-    if (rc) return rc;
-    const LobbyDev& lb = e->h_chains[mode * e->cfg.n_groups + group].lobby;
-    uint32_t k = 0;
-    for (uint32_t t = 0; t < e->cfg.modes[mode].teams; ++t)
-        for (uint32_t j = 0; j < lb.cnt[t] && j < 8; ++j) {
-            if (slots) slots[k] = lb.slot[t][j];
-            if (teams) teams[k] = (uint8_t)t;
-            ++k;
-        }
-    *n = k;
-    return MM_OK;
+    try {
+        if (!e || !n || mode >= e->cfg.n_modes || group >= e->cfg.n_groups) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        int rc = fetch_chains(e);
+        if (rc) return rc;
+        const LobbyDev& lb = e->h_chains[mode * e->cfg.n_groups + group].lobby;
+        uint32_t k = 0;
+        for (uint32_t t = 0; t < e->cfg.modes[mode].teams; ++t)
+            for (uint32_t j = 0; j < lb.cnt[t] && j < 8; ++j) {
+                if (slots) slots[k] = lb.slot[t][j];
+                if (teams) teams[k] = (uint8_t)t;
+                ++k;
+            }
+        *n = k;
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1920,113 +2010,131 @@ static unsigned long long snap_cfg_hash(const mm_config& c)
 
 extern "C" int mm_snapshot_size(mm_engine* e, uint64_t* bytes)
 {
-    if (!e || !bytes) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    int rc = fetch_chains(e);
-    if (rc) return rc;
-    uint64_t n = sizeof(SnapHeader) + e->cfg.capacity + (uint64_t)e->n_chains * sizeof(ChainDev);
-    for (uint32_t c = 0; c < e->n_chains; ++c) n += (uint64_t)e->h_chains[c].len * 12u;
-    *bytes = n;
-    return MM_OK;
+    try {
+        if (!e || !bytes) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        int rc = fetch_chains(e);
+        if (rc) return rc;
+        uint64_t n = sizeof(SnapHeader) + e->cfg.capacity + (uint64_t)e->n_chains * sizeof(ChainDev);
+        for (uint32_t c = 0; c < e->n_chains; ++c) n += (uint64_t)e->h_chains[c].len * 12u;
+        *bytes = n;
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
+    }
 }
 
 extern "C" int mm_snapshot(mm_engine* e, void* buf, uint64_t cap, uint64_t* written)
 {
-    if (!e || !buf || !written) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    uint64_t need = 0;
-    int rc = mm_snapshot_size(e, &need);                  // also refreshes h_chains
-    if (rc) return rc;
-    if (cap < need) return MM_ERR_RANGE;
-    unsigned char* out = (unsigned char*)buf;
-    SnapHeader h;
-    memset(&h, 0, sizeof(h));
-    h.magic = MM_SNAP_MAGIC;
-    h.version = 1;
-    h.abi = MM_ABI_VERSION;
-    h.header_bytes = (uint32_t)sizeof(SnapHeader);
-    h.capacity = e->cfg.capacity;
-    h.n_groups = e->cfg.n_groups;
-    h.n_modes = e->cfg.n_modes;
-    h.n_chains = e->n_chains;
-    h.next_slot = e->next_slot;
-    h.cancel_pending = e->cancel_pending;
-    h.chain_bytes = (uint32_t)sizeof(ChainDev);
-    h.live_upper = e->live_upper;
-    h.cfg_hash = snap_cfg_hash(e->cfg);
-    h.total_bytes = need;
-    size_t off = sizeof(SnapHeader);
-    memcpy(out + off, e->h_state.data(), e->cfg.capacity);                 // ActiveUser mirror
-    off += e->cfg.capacity;
-    memcpy(out + off, e->h_chains, (size_t)e->n_chains * sizeof(ChainDev)); // lengths + stored lobbies
-    off += (size_t)e->n_chains * sizeof(ChainDev);
-    const size_t cap_q = e->cfg.capacity;
-    for (uint32_t c = 0; c < e->n_chains; ++c) {                             // the queues, in order
-        const size_t len = e->h_chains[c].len;
-        if (!len) continue;
-        HIPCHK(e, hipMemcpyAsync(out + off, e->d_q_rating + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipMemcpyAsync(out + off + len * 4u, e->d_q_cons + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipMemcpyAsync(out + off + len * 8u, e->d_q_slot + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
-        off += len * 12u;
+    try {
+        if (!e || !buf || !written) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        uint64_t need = 0;
+        int rc = mm_snapshot_size(e, &need);                  // also refreshes h_chains
+        if (rc) return rc;
+        if (cap < need) return MM_ERR_RANGE;
+        unsigned char* out = (unsigned char*)buf;
+        SnapHeader h;
+        memset(&h, 0, sizeof(h));
+        h.magic = MM_SNAP_MAGIC;
+        h.version = 1;
+        h.abi = MM_ABI_VERSION;
+        h.header_bytes = (uint32_t)sizeof(SnapHeader);
+        h.capacity = e->cfg.capacity;
+        h.n_groups = e->cfg.n_groups;
+        h.n_modes = e->cfg.n_modes;
+        h.n_chains = e->n_chains;
+        h.next_slot = e->next_slot;
+        h.cancel_pending = e->cancel_pending;
+        h.chain_bytes = (uint32_t)sizeof(ChainDev);
+        h.live_upper = e->live_upper;
+        h.cfg_hash = snap_cfg_hash(e->cfg);
+        h.total_bytes = need;
+        size_t off = sizeof(SnapHeader);
+        memcpy(out + off, e->h_state.data(), e->cfg.capacity);                 // ActiveUser mirror
+        off += e->cfg.capacity;
+        memcpy(out + off, e->h_chains, (size_t)e->n_chains * sizeof(ChainDev)); // lengths + stored lobbies
+        off += (size_t)e->n_chains * sizeof(ChainDev);
+        const size_t cap_q = e->cfg.capacity;
+        for (uint32_t c = 0; c < e->n_chains; ++c) {                             // the queues, in order
+            const size_t len = e->h_chains[c].len;
+            if (!len) continue;
+            HIPCHK(e, hipMemcpyAsync(out + off, e->d_q_rating + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipMemcpyAsync(out + off + len * 4u, e->d_q_cons + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipMemcpyAsync(out + off + len * 8u, e->d_q_slot + c * cap_q, len * 4u, hipMemcpyDeviceToHost, e->stream));
+            off += len * 12u;
+        }
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        h.payload_hash = snap_hash(out + sizeof(SnapHeader), (size_t)need - sizeof(SnapHeader), 0xCBF29CE484222325ull);
+        memcpy(out, &h, sizeof(h));
+        *written = need;
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
     }
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    h.payload_hash = snap_hash(out + sizeof(SnapHeader), (size_t)need - sizeof(SnapHeader), 0xCBF29CE484222325ull);
-    memcpy(out, &h, sizeof(h));
-    *written = need;
-    return MM_OK;
 }
 
 extern "C" int mm_restore(mm_engine* e, const void* buf, uint64_t bytes)
 {
-    if (!e || !buf || bytes < sizeof(SnapHeader)) return MM_ERR_INVALID_ARG;
-    ON_ENGINE_DEVICE(e);
-    const unsigned char* in = (const unsigned char*)buf;
-    SnapHeader h;
-    memcpy(&h, in, sizeof(h));
-    if (h.magic != MM_SNAP_MAGIC || h.version != 1u || h.abi != MM_ABI_VERSION || h.header_bytes != sizeof(SnapHeader) ||
-        h.chain_bytes != sizeof(ChainDev) || h.total_bytes != bytes || h.capacity != e->cfg.capacity ||
-        h.n_groups != e->cfg.n_groups || h.n_modes != e->cfg.n_modes || h.n_chains != e->n_chains ||
-        h.cfg_hash != snap_cfg_hash(e->cfg))
-        return MM_ERR_INVALID_ARG;
-    if (h.payload_hash != snap_hash(in + sizeof(SnapHeader), (size_t)bytes - sizeof(SnapHeader), 0xCBF29CE484222325ull))
-        return MM_ERR_INVALID_ARG;
-    // structure check before anything is touched: the queue lengths have to add up
-    size_t off = sizeof(SnapHeader) + h.capacity;
-    const ChainDev* chains = (const ChainDev*)(in + off);
-    uint64_t need = off + (uint64_t)h.n_chains * sizeof(ChainDev);
-    for (uint32_t c = 0; c < h.n_chains; ++c) {
-        ChainDev cd;
-        memcpy(&cd, (const unsigned char*)chains + (size_t)c * sizeof(ChainDev), sizeof(cd));
-        if (cd.len > h.capacity) return MM_ERR_INVALID_ARG;
-        need += (uint64_t)cd.len * 12u;
+    try {
+        if (!e || !buf || bytes < sizeof(SnapHeader)) return MM_ERR_INVALID_ARG;
+        ON_ENGINE_DEVICE(e);
+        const unsigned char* in = (const unsigned char*)buf;
+        SnapHeader h;
+        memcpy(&h, in, sizeof(h));
+        if (h.magic != MM_SNAP_MAGIC || h.version != 1u || h.abi != MM_ABI_VERSION || h.header_bytes != sizeof(SnapHeader) ||
+            h.chain_bytes != sizeof(ChainDev) || h.total_bytes != bytes || h.capacity != e->cfg.capacity ||
+            h.n_groups != e->cfg.n_groups || h.n_modes != e->cfg.n_modes || h.n_chains != e->n_chains ||
+            h.cfg_hash != snap_cfg_hash(e->cfg))
+            return MM_ERR_INVALID_ARG;
+        if (h.payload_hash != snap_hash(in + sizeof(SnapHeader), (size_t)bytes - sizeof(SnapHeader), 0xCBF29CE484222325ull))
+            return MM_ERR_INVALID_ARG;
+        // structure check before anything is touched: the queue lengths have to add up
+        size_t off = sizeof(SnapHeader) + h.capacity;
+        const ChainDev* chains = (const ChainDev*)(in + off);
+        uint64_t need = off + (uint64_t)h.n_chains * sizeof(ChainDev);
+        for (uint32_t c = 0; c < h.n_chains; ++c) {
+            ChainDev cd;
+            memcpy(&cd, (const unsigned char*)chains + (size_t)c * sizeof(ChainDev), sizeof(cd));
+            if (cd.len > h.capacity) return MM_ERR_INVALID_ARG;
+            need += (uint64_t)cd.len * 12u;
+        }
+        if (need != bytes) return MM_ERR_INVALID_ARG;
+        int rc = mm_reset(e);
+        if (rc) return rc;
+        memcpy(e->h_state.data(), in + sizeof(SnapHeader), h.capacity);
+        HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state.data(), h.capacity, hipMemcpyHostToDevice, e->stream));
+        memcpy(e->h_chains, in + off, (size_t)h.n_chains * sizeof(ChainDev));
+        for (uint32_t c = 0; c < h.n_chains; ++c) {          // per-tick counters do not survive a restart
+            ChainDev& cd = e->h_chains[c];
+            cd.head_state = 0; cd.n_out = 0; cd.passes = 0; cd.err = 0; cd.purged = 0; cd.before = 0;
+            cd.pairs = 0; cd.scanned = 0;
+        }
+        HIPCHK(e, hipMemcpyAsync(e->d_chains, e->h_chains, (size_t)h.n_chains * sizeof(ChainDev), hipMemcpyHostToDevice, e->stream));
+        off += (size_t)h.n_chains * sizeof(ChainDev);
+        const size_t cap_q = e->cfg.capacity;
+        for (uint32_t c = 0; c < h.n_chains; ++c) {
+            const size_t len = e->h_chains[c].len;
+            if (!len) continue;
+            HIPCHK(e, hipMemcpyAsync(e->d_q_rating + c * cap_q, in + off, len * 4u, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->d_q_cons + c * cap_q, in + off + len * 4u, len * 4u, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->d_q_slot + c * cap_q, in + off + len * 8u, len * 4u, hipMemcpyHostToDevice, e->stream));
+            off += len * 12u;
+        }
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->next_slot = h.next_slot;
+        e->cancel_pending = h.cancel_pending;
+        e->live_upper = h.live_upper;
+        return MM_OK;
+    } catch (const std::bad_alloc&) {
+        return MM_ERR_OOM;
+    } catch (...) {
+        return MM_ERR_INTERNAL;
     }
-    if (need != bytes) return MM_ERR_INVALID_ARG;
-    int rc = mm_reset(e);
-    if (rc) return rc;
-    memcpy(e->h_state.data(), in + sizeof(SnapHeader), h.capacity);
-    HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state.data(), h.capacity, hipMemcpyHostToDevice, e->stream));
-    memcpy(e->h_chains, in + off, (size_t)h.n_chains * sizeof(ChainDev));
-    for (uint32_t c = 0; c < h.n_chains; ++c) {          // per-tick counters do not survive a restart
-        ChainDev& cd = e->h_chains[c];
-        cd.head_state = 0; cd.n_out = 0; cd.passes = 0; cd.err = 0; cd.purged = 0; cd.before = 0;
-        cd.pairs = 0; cd.scanned = 0;
-    }
-    HIPCHK(e, hipMemcpyAsync(e->d_chains, e->h_chains, (size_t)h.n_chains * sizeof(ChainDev), hipMemcpyHostToDevice, e->stream));
-    off += (size_t)h.n_chains * sizeof(ChainDev);
-    const size_t cap_q = e->cfg.capacity;
-    for (uint32_t c = 0; c < h.n_chains; ++c) {
-        const size_t len = e->h_chains[c].len;
-        if (!len) continue;
-        HIPCHK(e, hipMemcpyAsync(e->d_q_rating + c * cap_q, in + off, len * 4u, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(e, hipMemcpyAsync(e->d_q_cons + c * cap_q, in + off + len * 4u, len * 4u, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(e, hipMemcpyAsync(e->d_q_slot + c * cap_q, in + off + len * 8u, len * 4u, hipMemcpyHostToDevice, e->stream));
-        off += len * 12u;
-    }
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    e->next_slot = h.next_slot;
-    e->cancel_pending = h.cancel_pending;
-    e->live_upper = h.live_upper;
-    return MM_OK;
 }
 
 extern "C" int mm_last_hip_error(const mm_engine* e) { return e ? e->last_hip : 0; }

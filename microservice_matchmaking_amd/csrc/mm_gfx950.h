@@ -1,0 +1,21 @@
+// mm_gfx950.h — the few primitives of the kernels that are written in gfx950 ISA directly.
+// Included as <mm_gfx950.h>: the product build finds this file (-I. in csrc/Makefile); the CPU
+// fiber-shim build of the kernel source used by the logic tests puts its own file of the same
+// name first on the include path (tests/emu/mm_gfx950.h), so the kernel source itself carries
+// no test-only branches.
+#ifndef MM_GFX950_H
+#define MM_GFX950_H
+
+// keep a value alive in a vector register (a load whose result is only wanted in the cache)
+#define TW_SINK(v) asm volatile("" ::"v"(v))
+
+// one dword through the scalar cache (K$ -> L2): the dependent load of a pointer chase whose
+// address is wave-uniform
+static __device__ __forceinline__ uint32_t tw_sload(const uint32_t* p)
+{
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+#endif

@@ -1,0 +1,7 @@
+// tests/emu/mm_gfx950.h — TEST INFRASTRUCTURE ONLY: the plain-C++ stand-ins of
+// microservice_matchmaking_amd/csrc/mm_gfx950.h for the fiber-shim build (no ISA on a CPU).
+#ifndef MM_GFX950_H
+#define MM_GFX950_H
+#define TW_SINK(v) asm volatile("" ::"r"(v))
+static inline uint32_t tw_sload(const uint32_t* p) { return *p; }
+#endif

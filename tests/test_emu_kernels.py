@@ -8,6 +8,7 @@ import pytest
 
 from emu_engine import EmuEngine
 from helpers import assert_same_state, assert_same_tick, load_golden, random_scenario, run_golden_case
+from microservice_matchmaking_amd._abi import cons_make
 from microservice_matchmaking_amd.config import make_config, mode_1v1, mode_team
 from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5, make_pool
 
@@ -155,3 +156,38 @@ def test_emu_stream_laps_the_slot_ring_around_waiting_players(oracle_cls):
     from helpers import run_wrapping_stream
     laps, stepped = run_wrapping_stream(EmuEngine, oracle_cls, capacity=2048, ticks=60, per_tick=300)
     assert laps > 5 and stepped > 10, (laps, stepped)
+
+
+def enqueue_device_rejects_leave_their_slots_free(engine_cls, to_device):
+    """mm_enqueue_device with players the device refuses (mode not configured): only the accepted
+    players hold a slot.  A refused player's slot is FREE — mm_cancel ignores it (no purge is armed
+    for nothing) and the next batch that reaches it takes it."""
+    import ctypes as C
+    from microservice_matchmaking_amd._abi import MMEnqueueStats
+    cfg = make_config([mode_1v1(window=50)], capacity=64)
+    rating = np.full(40, 1000, np.int32) + np.arange(40, dtype=np.int32) * 100     # nobody fits anybody
+    cons = cons_make(np.where(np.arange(40) % 4 == 3, 5, 0), 0, 0, 0)              # every fourth: mode 5
+    with engine_cls(cfg) as e:
+        fn = e._lib.mm_enqueue_device
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(MMEnqueueStats)]
+        fn.restype = C.c_int
+        d_r, d_c, keep = to_device(rating, cons)
+        first, st = C.c_uint32(), MMEnqueueStats()
+        assert fn(e._h, 40, d_r, d_c, C.byref(first), C.byref(st)) == 0
+        assert (first.value, st.accepted, st.rejected) == (0, 30, 10)
+        e.cancel(np.arange(3, 40, 4, dtype=np.uint32))        # the refused players' slots: nobody is there
+        m = e.tick(0)
+        assert len(m) == 0 and m.stats["pool_after"] == 30
+        # 24 slots were never used + 10 slots of refused players = 34 free slots of 64
+        s = e.enqueue(np.full(34, 4500, np.int32) + np.arange(34, dtype=np.int32), np.zeros(34, np.uint32))
+        assert sorted(s.tolist()) == list(range(40, 64)) + list(range(3, 40, 4))
+        with pytest.raises(Exception):
+            e.enqueue(np.array([4600], np.int32), np.zeros(1, np.uint32))          # the pool is full now
+        del keep
+
+
+def test_emu_enqueue_device_rejects_leave_their_slots_free():
+    def host_is_device(rating, cons):                         # under the shim device memory is host memory
+        return rating.ctypes.data_as(C.c_void_p), cons.ctypes.data_as(C.c_void_p), (rating, cons)
+    import ctypes as C
+    enqueue_device_rejects_leave_their_slots_free(EmuEngine, host_is_device)

@@ -20,3 +20,14 @@ def test_gpu_stream_laps_the_slot_ring_around_waiting_players(gpu_cls, oracle_cl
     from helpers import run_wrapping_stream
     laps, stepped = run_wrapping_stream(gpu_cls, oracle_cls, capacity=4096, ticks=150, per_tick=600)
     assert laps > 10 and stepped > 20, (laps, stepped)
+
+
+def test_gpu_enqueue_device_rejects_leave_their_slots_free(gpu_cls):
+    import ctypes as C
+    import torch
+    from test_emu_kernels import enqueue_device_rejects_leave_their_slots_free
+
+    def to_device(rating, cons):
+        d_r, d_c = torch.from_numpy(rating).cuda(), torch.from_numpy(cons.view("int32")).cuda()
+        return C.c_void_p(d_r.data_ptr()), C.c_void_p(d_c.data_ptr()), (d_r, d_c)
+    enqueue_device_rejects_leave_their_slots_free(gpu_cls, to_device)
