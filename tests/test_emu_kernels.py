@@ -180,7 +180,7 @@ def enqueue_device_rejects_leave_their_slots_free(engine_cls, to_device):
         assert len(m) == 0 and m.stats["pool_after"] == 30
         # 24 slots were never used + 10 slots of refused players = 34 free slots of 64
         s = e.enqueue(np.full(34, 4500, np.int32) + np.arange(34, dtype=np.int32), np.zeros(34, np.uint32))
-        assert sorted(s.tolist()) == list(range(40, 64)) + list(range(3, 40, 4))
+        assert s.tolist() == list(range(40, 64)) + list(range(3, 40, 4))   # ring order from next_slot = 40
         with pytest.raises(Exception):
             e.enqueue(np.array([4600], np.int32), np.zeros(1, np.uint32))          # the pool is full now
         del keep
