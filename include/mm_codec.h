@@ -68,16 +68,24 @@ int mm_decode_players(const mm_config* cfg, const mm_codec_cfg* cc, const char* 
  * section 1).
  *
  * Input: the L = teams * team_size payloads of one lobby in mm_matches order (team major,
- * seating order inside the team), as they were delivered.  Output: one JSON object.  Members
- * are written in ascending key order on the three levels this function builds (the lobby, the
- * teams map, each player; a duplicate key keeps its last value, as a map would); member names
- * are written with the minimal escapes; every player VALUE — numbers, strings, nested
- * objects — is copied byte for byte from the payload, so nothing is re-formatted.
+ * seating order inside the team), as they were delivered.  Output: one JSON object — the bytes
+ * Poison 4.0.1 (reference mix.lock:17) writes for that map.  Poison decodes and re-encodes, so
+ * every value is re-written in its canonical form, on every level:
+ *   objects  members in DESCENDING bytewise key order (Poison.Encoder.Map folds :maps.keys/1 —
+ *            ascending for maps of <= 32 keys — with a prepend); a duplicate member keeps its last
+ *            value; hence {"teams":{"team 2":[..],"team 1":[..]},"game-mode":".."}
+ *   arrays   order kept (Poison.Encoder.List, foldr)
+ *   strings  escapes resolved, then \" \\ \n \t \r \f \b, other bytes <= 0x1F and 0x7F as \u00XX with
+ *            uppercase hex digits, everything else (UTF-8, "/") raw  (Poison.Encoder.BitString)
+ *   integers the digits ("-0" is 0); a number with a fraction or an exponent is a float and is
+ *            written as :io_lib_format.fwrite_g/1 writes it (2500.5, 100.0, 1.0e3, 0.001, 1.0e-5)
  *
- * Equivalence bar: the output decodes to exactly the map the reference builds (checked with
- * Python's json against a dict-level restatement, tests/test_codec.py).  Byte identity with
- * Poison's own output is NOT claimed: the key order of Poison's map encoder and its float
- * formatting cannot be pinned in this container, and the consumer decodes anyway.
+ * Equivalence bar: byte identity with Poison.encode! for objects of up to 32 members per level
+ * (beyond that the VM's hash order decides :maps.keys/1, which cannot be restated; such an object is
+ * still written in descending order and decodes to the same map).  Pinned by hand-derived golden
+ * strings and an independent Python restatement of the same Poison / OTP sources
+ * (tests/test_codec.py); no BEAM exists in this image to run Poison itself, and the consumer
+ * (lib/game-lobby/worker.ex:119-127) decodes the message anyway.
  *
  * *written = bytes needed; MM_ERR_RANGE if cap is smaller (nothing useful in out then);
  * MM_ERR_INVALID_ARG for a payload that is not a JSON object or bad arguments. */

@@ -41,6 +41,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <cmath>
 #include <new>
 #include <vector>
 

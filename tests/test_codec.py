@@ -190,39 +190,119 @@ def lobby_as_the_reference_builds_it(game_mode, teams, team_size, payloads):
             "game-mode": game_mode}
 
 
-def test_lobby_decodes_to_the_map_the_reference_publishes(lib):
+# Poison 4.0.1 (reference mix.lock:17) as an independent Python restatement of its encoder rules
+# (the C++ in csrc/mm_codec.inc restates the same sources; neither could be run against a BEAM here):
+#   Poison.Encoder.Map    `:lists.foldl(&[?,, key, ?:, value | &2], [], :maps.keys(map))` -> REVERSE of
+#                         :maps.keys/1, which is ascending term (bytewise) order for <= 32 keys
+#   Poison.Encoder.List   `:lists.foldr` -> order kept
+#   Poison.Encoder.BitString (default)  \" \\ \n \t \r \f \b, other bytes <= 0x1F and 0x7F as \u00XX
+#                         (uppercase hex), the rest raw
+#   Integer               Integer.to_string;  Float  :io_lib_format.fwrite_g/1
+def fwrite_g(v: float) -> str:
+    """OTP io_lib_format:fwrite_g/1 + insert_decimal/2, digits from Python's shortest repr."""
+    import math
+    if v == 0.0:
+        return "-0.0" if math.copysign(1.0, v) < 0 else "0.0"
+    sign, a = ("-" if v < 0 else ""), abs(v)
+    mant, _, exp = ("%r" % a if "e" in "%r" % a else "%.17e" % a).partition("e")
+    if "e" not in "%r" % a:                                  # repr in fixed notation: take the digits from it
+        txt = "%r" % a
+        ip, _, fp = txt.partition(".")
+        digits = (ip + fp).lstrip("0")
+        place = len(ip.lstrip("0")) if ip.strip("0") else -(len(fp) - len(fp.lstrip("0")))
+        digits = digits.rstrip("0") or "0"
+    else:
+        digits = mant.replace(".", "").rstrip("0") or "0"
+        place = int(exp) + 1
+    L = len(digits)
+    expl = str(place - 1)
+
+    def with_exp():
+        return digits[0] + "." + (digits[1:] if L > 1 else "0") + "e" + expl
+    if place == 0:
+        return sign + "0." + digits
+    if place < 0 or place >= L:
+        cost = len(expl) + 1 + (2 if L == 1 else 1)
+        if place < 0:
+            return sign + ("0." + "0" * -place + digits if 2 - place <= cost else with_exp())
+        return sign + (digits + "0" * (place - L) + ".0" if place - L + 2 <= cost else with_exp())
+    return sign + digits[:place] + "." + digits[place:]
+
+
+def poison_string(t: str) -> str:
+    out = ['"']
+    short = {'"': '\\"', "\\": "\\\\", "\n": "\\n", "\t": "\\t", "\r": "\\r", "\f": "\\f", "\b": "\\b"}
+    for ch in t:
+        o = ord(ch)
+        out.append(short[ch] if ch in short else ("\\u%04X" % o if (o <= 0x1F or o == 0x7F) else ch))
+    return "".join(out) + '"'
+
+
+def poison_encode(v) -> str:
+    if isinstance(v, dict):
+        keys = sorted(v, key=lambda k: k.encode("utf-8"), reverse=True)
+        return "{" + ",".join(poison_string(k) + ":" + poison_encode(v[k]) for k in keys) + "}"
+    if isinstance(v, list):
+        return "[" + ",".join(poison_encode(x) for x in v) + "]"
+    if isinstance(v, str):
+        return poison_string(v)
+    if v is True or v is False or v is None:
+        return {True: "true", False: "false", None: "null"}[v]
+    return str(v) if isinstance(v, int) else fwrite_g(v)
+
+
+def test_fwrite_g_restatement_on_the_known_cases():
+    # the shell prints these (OTP io_lib_format): fixed notation unless the exponent form is strictly shorter
+    for v, want in ((1.0, "1.0"), (100.0, "100.0"), (1000.0, "1.0e3"), (2500.5, "2500.5"), (0.001, "0.001"),
+                    (0.00001, "1.0e-5"), (0.00012, "1.2e-4"), (1.5e10, "1.5e10"), (123456789.0, "123456789.0"),
+                    (-0.5, "-0.5"), (1e22, "1.0e22"), (5e-324, "5.0e-324"), (0.1 + 0.2, "0.30000000000000004"),
+                    (12345.678, "12345.678"), (1e-7, "1.0e-7"), (-0.0, "-0.0")):
+        assert fwrite_g(v) == want, (v, fwrite_g(v))
+
+
+def test_lobby_is_poison_encode_of_the_map_the_reference_publishes(lib):
     rng = np.random.default_rng(3)
     for teams, team_size in ((2, 1), (2, 5), (3, 2), (4, 4)):
         payloads = []
         for k in range(teams * team_size):
-            d = {"id": "p-%d-é\"\\\n中" % k, "rating": int(rng.integers(0, 5001)), "game-mode": "5v5 ranked",
+            d = {"id": "p-%d-é\"\\\n中\x7f/" % k, "rating": int(rng.integers(0, 5001)), "game-mode": "5v5 ranked",
                  "response-queue": "amq.gen-%d" % k, "event-name": "find-game",
-                 "detail": {"z": [1, 2.50, None, True], "a": {"game-mode": "kept: nested"}}, "role": k % 5,
-                 "weird \u00e9 key\t": 1e-7, "big": 123456789012345678901234567890}
+                 "detail": {"z": [1, 2.50, None, True, -0.0, 1e3, 1e-7], "a": {"game-mode": "kept: nested"}, "": []},
+                 "role": k % 5, "weird \u00e9 key\t": 1e-7, "big": 123456789012345678901234567890,
+                 "f": float(rng.normal()) * 10.0 ** int(rng.integers(-8, 9))}
             items = list(d.items())
             rng.shuffle(items)
             payloads.append(json.dumps(dict(items), ensure_ascii=bool(k & 1), separators=[(",", ":"), (" , ", " : ")][k & 1]).encode("utf-8"))
         out = encode_lobby(lib, "5v5 ranked", teams, team_size, payloads)
-        assert json.loads(out.decode("utf-8")) == lobby_as_the_reference_builds_it("5v5 ranked", teams, team_size, payloads)
-        # the three levels this function builds: ascending keys, no insignificant whitespace
-        assert out.startswith(b'{"game-mode":"5v5 ranked","teams":{"team 1":[{')
+        want = lobby_as_the_reference_builds_it("5v5 ranked", teams, team_size, payloads)
+        assert json.loads(out.decode("utf-8")) == want                      # the consumer's view: map equality
+        assert out.decode("utf-8") == poison_encode(want)                  # and the bytes Poison.encode! writes
+        # descending keys on every level (Poison.Encoder.Map folds :maps.keys with a prepend)
+        assert out.startswith(b'{"teams":{"team %d":[{' % teams) and out.endswith(b'},"game-mode":"5v5 ranked"}')
         top = json.loads(out.decode("utf-8"), object_pairs_hook=list)
-        assert [k for k, _ in top] == ["game-mode", "teams"]
-        assert [k for k, _ in top[1][1]] == ["team %d" % (t + 1) for t in range(teams)]
-        for _, players in top[1][1]:
+        assert [k for k, _ in top] == ["teams", "game-mode"]
+        assert [k for k, _ in top[0][1]] == ["team %d" % (t + 1) for t in reversed(range(teams))]
+        for _, players in top[0][1]:
             for pl in players:
                 keys = [k.encode("utf-8") for k, _ in pl]
-                assert keys == sorted(keys) and b"game-mode" not in keys
+                assert keys == sorted(keys, reverse=True) and b"game-mode" not in keys
         # required slots as the lobby worker counts them (game-lobby/worker.ex:37-39)
         assert sum(len(v) for v in json.loads(out.decode("utf-8"))["teams"].values()) == teams * team_size
 
 
-def test_lobby_values_are_copied_byte_for_byte(lib):
-    a = b'{"rating":1.50e3,"id":"\\u0041\\/b","game-mode":"duel","n":{"y" : 1 ,"x":[ 1,2 ]},"rating":7}'
-    b = b' { "id" : 2 , "g\\u0061me-mode" : "duel" , "k\\"ey" : -0.0 } '
+def test_lobby_golden_bytes(lib):
+    """Hand-derived from the rules above (Poison 4.0.1 lib/poison/encoder.ex, OTP io_lib_format.erl):
+    a: members rating (twice: the last wins), id, game-mode (popped, worker.ex:294), n -> descending: rating, n, id;
+       "\\u0041\\/b" decodes to "A/b" and is written raw; 1.50e3 would be the float 1.5e3 but the later 7 replaces it;
+       n = %{"y" => 1, "x" => [1, 2]} -> y before x.
+    b: "g\\u0061me-mode" IS "game-mode" (popped); -0.0 stays a float; 1e3 -> 1.0e3; "\\u001f" -> \\u001F; "\\u007f" -> \\u007F;
+       -0 -> 0; 12.50 -> 12.5; keys k"ey > id > f > e > d > c."""
+    a = b'{"rating":1.50e3,"id":"\\u0041\\/b","game-mode":"duel","n":{"x":[ 1,2 ],"y" : 1 },"rating":7}'
+    b = (b' { "id" : 2 , "g\\u0061me-mode" : "duel" , "k\\"ey" : -0.0 , "c" : 1e3 , "d" : "\\u001f\\u007f\\n" , '
+         b'"e" : -0 , "f" : 12.50 } ')
     out = encode_lobby(lib, 'du"el', 2, 1, [a, b])
-    assert out == (b'{"game-mode":"du\\"el","teams":{"team 1":[{"id":"\\u0041\\/b","n":{"y" : 1 ,"x":[ 1,2 ]},"rating":7}],'
-                   b'"team 2":[{"id":2,"k\\"ey":-0.0}]}}')
+    assert out == (b'{"teams":{"team 2":[{"k\\"ey":-0.0,"id":2,"f":12.5,"e":0,"d":"\\u001F\\u007F\\n","c":1.0e3}],'
+                   b'"team 1":[{"rating":7,"n":{"y":1,"x":[1,2]},"id":"A/b"}]},"game-mode":"du\\"el"}')
 
 
 def test_lobby_refuses_what_is_not_a_player_object(lib):
@@ -232,3 +312,51 @@ def test_lobby_refuses_what_is_not_a_player_object(lib):
             encode_lobby(lib, "duel", 2, 1, [good, bad])
     with pytest.raises(MMError):
         encode_lobby(lib, "duel", 5, 4, [good] * 20)           # more than MM_MAX_LOBBY seats
+
+
+# ---- the codec in the driver's `-m gpu` tier: the code that ships in libmm_engine.so, end to end ----
+
+@pytest.mark.gpu
+def test_gpu_deliveries_to_published_lobbies(lib, oracle_cls):
+    """generic/worker.ex:55-69 -> search/worker.ex:291-324 -> :315-318 on the product library:
+    JSON deliveries are decoded in one call, enqueued with the exact-rating group override, searched
+    on the GPU, and every emitted lobby is encoded from its players' payloads.  Checked against the
+    oracle (who is in which lobby) and the Poison restatement (the published bytes)."""
+    from microservice_matchmaking_amd import Engine
+    rng = np.random.default_rng(11)
+    msgs = []
+    for k in range(6000):
+        d = {"id": "user-%05d" % k, "rating": int(rng.integers(1000, 1400)) if k % 97 else 1234.5,
+             "game-mode": MODES[int(rng.random() < 0.3)], "response-queue": "amq.gen-%d" % k,
+             "event-name": "find-game", "region": int(rng.integers(0, 2)), "role": int(rng.integers(0, 5))}
+        if d["game-mode"] == "duel":
+            d.pop("role")
+        msgs.append(json.dumps(d).encode())
+    out = decode_players(lib, CFG, MODES, msgs, region_key="region", party_key="party", role_key="role")
+    keep = np.isin(out["status"], (DEC_OK, DEC_RATING_INEXACT, DEC_RATING_NOT_NUMBER))
+    assert keep.all() and int((out["status"] == DEC_RATING_INEXACT).sum()) == len(range(0, 6000, 97))
+    cfg = make_config([mode_1v1(window=25, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 13)
+    with Engine(cfg) as gpu, oracle_cls(cfg) as cpu:
+        sg = gpu.enqueue(out["rating"], out["cons"], out["group"])
+        sc = cpu.enqueue(out["rating"], out["cons"], out["group"])
+        assert np.array_equal(sg, sc)
+        by_slot = {int(s): m for s, m in zip(sg, msgs)}
+        n_lobbies = 0
+        for mode, (teams, team_size) in enumerate(((2, 1), (2, 5))):
+            mg, mc = gpu.tick(mode), cpu.tick(mode)
+            assert np.array_equal(mg.slots, mc.slots) and len(mg) > 0
+            for row in mg.slots[:: max(1, len(mg) // 200)]:
+                payloads = [by_slot[int(s)] for s in row]
+                js = encode_lobby(lib, MODES[mode], teams, team_size, payloads)
+                want = lobby_as_the_reference_builds_it(MODES[mode], teams, team_size, payloads)
+                assert js.decode("utf-8") == poison_encode(want)
+                n_lobbies += 1
+        assert n_lobbies > 100
+
+
+@pytest.mark.gpu
+def test_gpu_tier_runs_the_decode_edge_cases(lib):
+    msgs = [b'{"id":"a","rating":1499.5,"game-mode":"duel"}', b'{"id":1,"rating":null,"game-mode":"duel"}',
+            b'{"id":"x","rating":1e3,"game-mode":"5v5 ranked","role":4}', b'{"rating":5,"game-mode":"nope"}',
+            b'{"rating":5,"game-mode":"duel","region":256}', b'[1]', b'{"id":"\\ud83d\\ude00","rating":2147483648,"game-mode":"duel"}']
+    check(lib, msgs)
