@@ -912,6 +912,7 @@ struct mm_engine {
     uint16_t* d_pk_exa[2];
     uint32_t* d_pk_bitsp[2];
     uint32_t* d_pk_headp[2];
+    uint32_t* d_pk_cand[2];
     bool pair_fused;           // MM_PAIR_FUSED=0: three launches per round instead of one (A/B testing)
     uint32_t round_ctr;
     uint32_t* d_pk_tilectl;
@@ -1126,7 +1127,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_pk_wpre);
     (void)hipFree(e->d_pk_g16);
     (void)hipFree(e->d_pk_rec1);
-    for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); }
+    for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); (void)hipFree(e->d_pk_cand[b]); }
     (void)hipFree(e->d_pk_tilectl);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_tchains) (void)hipHostFree(e->h_tchains);
@@ -1243,6 +1244,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
                 CREATE_CHK(hipMalloc((void**)&e->d_pk_exa[b], (gc + 64) * sizeof(uint16_t)));
                 CREATE_CHK(hipMalloc((void**)&e->d_pk_bitsp[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
                 CREATE_CHK(hipMalloc((void**)&e->d_pk_headp[b], (size_t)cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_pk_cand[b], (size_t)cfg->n_groups * e->pk_max_tiles * PW_C * sizeof(uint32_t)));
             }
             CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
@@ -1545,7 +1547,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     P.g16 = e->d_pk_g16;
     P.rec2[0] = e->d_pk_scratch;
     P.rec2[1] = e->d_pk_rec1;
-    for (int b = 0; b < 2; ++b) { P.exa[b] = e->d_pk_exa[b]; P.bitsp[b] = e->d_pk_bitsp[b]; P.headp[b] = e->d_pk_headp[b]; }
+    for (int b = 0; b < 2; ++b) { P.exa[b] = e->d_pk_exa[b]; P.bitsp[b] = e->d_pk_bitsp[b]; P.headp[b] = e->d_pk_headp[b]; P.cand[b] = e->d_pk_cand[b]; }
     P.tilectl = e->d_pk_tilectl;
     P.max_tiles = e->pk_max_tiles;
     P.out_slots = e->d_out_slots;
@@ -1808,10 +1810,22 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                     g, hp[g].fast, hp[g].m, hp[g].qlen, hp[g].passes, hp[g].n_out, hp[g].rounds, hp[g].dbg[0], hp[g].dbg[1],
                     hp[g].dbg[2], hp[g].dbg[3], hp[g].dbg[4], hp[g].dbg[5], hp[g].dbg[6], hp[g].dbg[7]);
         for (uint32_t g = 0; g < G; ++g)
-            if (hp[g].rounds)
-                fprintf(stderr, "[mm-pair] g%u tile1 cycles/round (fused: load %u walk+stage %u apply %u | repair %u build %u resolve %u publish+head %u)\n",
-                        g, hp[g].tm[0] / hp[g].rounds, hp[g].tm[6] / hp[g].rounds, hp[g].tm[9] / hp[g].rounds,
-                        hp[g].tm[1] / hp[g].rounds, hp[g].tm[2] / hp[g].rounds, hp[g].tm[3] / hp[g].rounds, hp[g].tm[4] / hp[g].rounds);
+            if (hp[g].rounds) {
+                const uint32_t nr = e->pair_fused ? (hp[g].tm[5] ? hp[g].tm[5] : 1u) : hp[g].rounds;
+                if (e->pair_fused)
+                    fprintf(stderr, "[mm-pair] g%u tile1 cycles/round over %u rounds (load %u walk+stage+sweepA %u apply %u | detect %u items %u long %u (%.1f long items) | graph %u resolve %u publish %u | cand+head %u)\n",
+                            g, nr, hp[g].tm[0] / nr, hp[g].tm[6] / nr, hp[g].tm[9] / nr, hp[g].tm[1] / nr, hp[g].tm[12] / nr, hp[g].tm[2] / nr,
+                            (double)hp[g].tm[11] / nr, hp[g].tm[7] / nr, hp[g].tm[8] / nr, hp[g].tm[10] / nr, hp[g].tm[4] / nr);
+                else
+                    fprintf(stderr, "[mm-pair] g%u tile1 cycles/round over %u rounds (load %u route %u apply %u | repair %u build %u resolve %u publish %u)\n",
+                            g, nr, hp[g].tm[0] / nr, hp[g].tm[7] / nr, hp[g].tm[9] / nr,
+                            hp[g].tm[1] / nr, hp[g].tm[2] / nr, hp[g].tm[3] / nr, hp[g].tm[4] / nr);
+            }
+        if (e->pair_tune & 0x2000u)
+            for (uint32_t g = 0; g < G; ++g)
+                if (hp[g].rounds)
+                    fprintf(stderr, "[mm-pair] g%u wave-0 detect cycles(+hops) %u, wave-0 item cycles %u, sweepB items of tile 1 %u, all waves scan4 rounds %u\n",
+                            g, hp[g].tm[12], hp[g].tm[13], hp[g].tm[14], hp[g].tm[15]);
     }
 
     uint32_t total = 0, after = 0, before = 0, pmax = 0, errf = 0;

@@ -10,7 +10,8 @@ import os
 from ._abi import EngineBase, MMConfig, MMEnqueueStats, MMError, bind
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmm_engine.so")
+# MM_ENGINE_LIB: another build of the SAME library (tile geometry experiments, tools/ab_bench.py); never a CPU path
+LIB_PATH = os.environ.get("MM_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libmm_engine.so")
 _lib = None
 
 

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("bench_args", nargs="*", help="after --: passed to bench.py")
     a = ap.parse_args()
-    base_args = ["--no-cpu-baseline", "--no-stream"] + a.bench_args
+    base_args = ["--no-cpu-baseline", "--no-stream", "--no-secondary"] + a.bench_args
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     out_path = os.path.join(ROOT, "gpurun_out", "ab_%s.jsonl" % a.tag)
     rows = []
