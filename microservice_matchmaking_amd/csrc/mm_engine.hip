@@ -912,7 +912,6 @@ struct mm_engine {
     uint16_t* d_pk_exa[2];
     uint32_t* d_pk_bitsp[2];
     uint32_t* d_pk_headp[2];
-    uint32_t* d_pk_cand[2];
     bool pair_fused;           // MM_PAIR_FUSED=0: three launches per round instead of one (A/B testing)
     uint32_t round_ctr;
     uint32_t* d_pk_tilectl;
@@ -922,6 +921,7 @@ struct mm_engine {
     bool force_generic;        // MM_FORCE_GENERIC=1: always walk with k_walk (A/B testing)
     bool pair_debug;           // MM_PAIR_DEBUG=1: print the pair path's diagnostics per tick
     uint32_t pair_tune;        // MM_PAIR_TUNE: PairParams.tune
+    bool pair_tile_fixed;      // MM_PAIR_TILE=max: every batch with the largest tile length (A/B)
     unsigned long long live_upper;   // upper bound of queued players (grid sizing)
     // team path (mm_team.inc): shares the pair path's arrays, plus
     TeamChain* d_tchains;
@@ -1127,7 +1127,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_pk_wpre);
     (void)hipFree(e->d_pk_g16);
     (void)hipFree(e->d_pk_rec1);
-    for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); (void)hipFree(e->d_pk_cand[b]); }
+    for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); }
     (void)hipFree(e->d_pk_tilectl);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_tchains) (void)hipHostFree(e->h_tchains);
@@ -1182,6 +1182,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_debug = pd && pd[0] == '1';
             const char* pt = getenv("MM_PAIR_TUNE");
             e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
+            const char* ptl = getenv("MM_PAIR_TILE");
+            e->pair_tile_fixed = ptl && ptl[0] == 'm';
             const char* pf = getenv("MM_PAIR_FUSED");
             e->pair_fused = !(pf && pf[0] == '0');
             e->round_ctr = 0;
@@ -1230,7 +1232,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const size_t gc = (size_t)cfg->n_groups * e->pk_stride;
             e->pk_bits_stride = (uint32_t)(cap / 32 + 4);
             CREATE_CHK(hipMalloc((void**)&e->d_pchains, cfg->n_groups * sizeof(PairChain)));
-            e->pk_max_tiles = (uint32_t)(cap / PK_T + 2);
+            e->pk_max_tiles = (uint32_t)(cap / (PK_TMAX / 4u) + 2);   // tiles of the smallest tile length
             for (int b = 0; b < 2; ++b) {
                 CREATE_CHK(hipMalloc((void**)&e->d_pk_key[b], (gc + 64) * sizeof(uint32_t)));
                 CREATE_CHK(hipMalloc((void**)&e->d_pk_oidx[b], gc * sizeof(uint32_t)));
@@ -1244,7 +1246,6 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
                 CREATE_CHK(hipMalloc((void**)&e->d_pk_exa[b], (gc + 64) * sizeof(uint16_t)));
                 CREATE_CHK(hipMalloc((void**)&e->d_pk_bitsp[b], (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
                 CREATE_CHK(hipMalloc((void**)&e->d_pk_headp[b], (size_t)cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
-                CREATE_CHK(hipMalloc((void**)&e->d_pk_cand[b], (size_t)cfg->n_groups * e->pk_max_tiles * PW_C * sizeof(uint32_t)));
             }
             CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
@@ -1547,7 +1548,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     P.g16 = e->d_pk_g16;
     P.rec2[0] = e->d_pk_scratch;
     P.rec2[1] = e->d_pk_rec1;
-    for (int b = 0; b < 2; ++b) { P.exa[b] = e->d_pk_exa[b]; P.bitsp[b] = e->d_pk_bitsp[b]; P.headp[b] = e->d_pk_headp[b]; P.cand[b] = e->d_pk_cand[b]; }
+    for (int b = 0; b < 2; ++b) { P.exa[b] = e->d_pk_exa[b]; P.bitsp[b] = e->d_pk_bitsp[b]; P.headp[b] = e->d_pk_headp[b]; }
     P.tilectl = e->d_pk_tilectl;
     P.max_tiles = e->pk_max_tiles;
     P.out_slots = e->d_out_slots;
@@ -1579,12 +1580,26 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 longest = pc.m > longest ? pc.m : longest;
             }
             if (!tiled) break;
-            tiles = (longest + PK_T - 1u) / PK_T;
+            // tile length of this batch: the smallest that keeps the longest chain within PK_TILES_MAX tiles (the
+            // walk costs one dependent load per tile, everything else is proportional to the tile); the
+            // three-launch form of a round (MM_PAIR_FUSED=0) stays with the largest
+            uint32_t tp = PK_TMAX;
+            if (e->pair_fused && !e->pair_tile_fixed) {
+                if ((longest + PK_TMAX / 4u - 1u) / (PK_TMAX / 4u) <= PK_TILES_MAX) tp = PK_TMAX / 4u;
+                else if ((longest + PK_TMAX / 2u - 1u) / (PK_TMAX / 2u) <= PK_TILES_MAX) tp = PK_TMAX / 2u;
+            }
+            tiles = (longest + tp - 1u) / tp;
+#define TILE_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                                              \
+    do {                                                                                                                   \
+        if (tp == PK_TMAX) hipLaunchKernelGGL(KERNEL<PK_TMAX>, GRID, BLOCK, 0, e->stream, __VA_ARGS__);                    \
+        else if (tp == PK_TMAX / 2u) hipLaunchKernelGGL(KERNEL<PK_TMAX / 2u>, GRID, BLOCK, 0, e->stream, __VA_ARGS__);     \
+        else hipLaunchKernelGGL(KERNEL<PK_TMAX / 4u>, GRID, BLOCK, 0, e->stream, __VA_ARGS__);                             \
+    } while (0)
             if (compact) {
-                hipLaunchKernelGGL(kc_words, dim3(tiles, G), dim3(256), 0, e->stream, P);
-                hipLaunchKernelGGL(kc_plan, dim3(G), dim3(1024), 0, e->stream, P);
-                hipLaunchKernelGGL(kc_scatter, dim3(tiles, G), dim3(1024), 0, e->stream, P);
-                hipLaunchKernelGGL(kc_commit, dim3(G), dim3(1024), 0, e->stream, P);
+                TILE_LAUNCH(kc_words, dim3(tiles, G), dim3(256), P);
+                TILE_LAUNCH(kc_plan, dim3(G), dim3(1024), P);
+                TILE_LAUNCH(kc_scatter, dim3(tiles, G), dim3(1024), P);
+                TILE_LAUNCH(kc_commit, dim3(G), dim3(1024), P);
                 HIPCHK(e, hipGetLastError());
                 continue;                       // look at the new lengths before the next batch
             }
@@ -1592,11 +1607,11 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 // one launch per pass; the first of a batch only prepares, the commit brings the
                 // latest parity back into the chains' committed state
                 uint32_t r = e->round_ctr;
-                hipLaunchKernelGGL(kp_round, dim3(tiles, G), dim3(PT_THREADS), 0, e->stream, P, r, 1u);
+                TILE_LAUNCH(kp_round, dim3(tiles, G), dim3(PT_THREADS), P, r, 1u);
                 ++r;
                 for (uint32_t b = 0; b < e->pair_batch; ++b, ++r)
-                    hipLaunchKernelGGL(kp_round, dim3(tiles, G), dim3(PT_THREADS), 0, e->stream, P, r, 0u);
-                hipLaunchKernelGGL(kp_round_commit, dim3(tiles, G), dim3(256), 0, e->stream, P, r);
+                    TILE_LAUNCH(kp_round, dim3(tiles, G), dim3(PT_THREADS), P, r, 0u);
+                TILE_LAUNCH(kp_round_commit, dim3(tiles, G), dim3(256), P, r);
                 hipLaunchKernelGGL(kp_round_stage, dim3(G), dim3(64), 0, e->stream, P, r);
                 e->round_ctr = r;
             } else {
@@ -1606,6 +1621,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                     hipLaunchKernelGGL(kp_tile_apply, dim3(tiles, G), dim3(PA_THREADS), 0, e->stream, P);
                 }
             }
+#undef TILE_LAUNCH
             HIPCHK(e, hipGetLastError());
         }
     }
@@ -1821,11 +1837,23 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                             g, nr, hp[g].tm[0] / nr, hp[g].tm[7] / nr, hp[g].tm[9] / nr,
                             hp[g].tm[1] / nr, hp[g].tm[2] / nr, hp[g].tm[3] / nr, hp[g].tm[4] / nr);
             }
+        if (e->pair_tune & 0x2000u) {
+            std::vector<uint32_t> xc(e->pk_max_tiles);
+            HIPCHK(e, hipMemcpy(xc.data(), e->d_pk_tilectl + ((size_t)TC_DISP * G + 0) * e->pk_max_tiles,
+                                e->pk_max_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[mm-pair] g0 XCD of tile 0..47's workgroup at its last round:");
+            for (uint32_t t = 0; t < 48 && t < e->pk_max_tiles; ++t) fprintf(stderr, " %u", xc[t] & 0xFu);
+            fprintf(stderr, "\n");
+        }
         if (e->pair_tune & 0x2000u)
             for (uint32_t g = 0; g < G; ++g)
                 if (hp[g].rounds)
-                    fprintf(stderr, "[mm-pair] g%u wave-0 detect cycles(+hops) %u, wave-0 item cycles %u, sweepB items of tile 1 %u, all waves scan4 rounds %u\n",
-                            g, hp[g].tm[12], hp[g].tm[13], hp[g].tm[14], hp[g].tm[15]);
+                    fprintf(stderr, "[mm-pair] g%u walk loop of tile 1's workgroup: %u iterations, %.0f cycles each (%.0f cycles per timed round)\n",
+                            g, hp[g].tm[15], hp[g].tm[15] ? 16.0 * hp[g].tm[13] / hp[g].tm[15] : 0.0,
+                            16.0 * hp[g].tm[13] / (hp[g].tm[5] ? hp[g].tm[5] : 1u));
+        if (e->pair_tune & 0x2000u)
+            fprintf(stderr, "[mm-pair] g0 walk: cycles in iterations 1-4 per round %.0f, in the later ones %.0f\n",
+                    16.0 * hp[0].tm[12] / (hp[0].tm[5] ? hp[0].tm[5] : 1u), 16.0 * hp[0].tm[14] / (hp[0].tm[5] ? hp[0].tm[5] : 1u));
     }
 
     uint32_t total = 0, after = 0, before = 0, pmax = 0, errf = 0;

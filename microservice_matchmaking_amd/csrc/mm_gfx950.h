@@ -18,4 +18,20 @@ static __device__ __forceinline__ uint32_t tw_sload(const uint32_t* p)
     return v;
 }
 
+
+// two independent dwords through the scalar cache, one wait: both addresses wave-uniform
+static __device__ __forceinline__ void tw_sload2(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1)
+{
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1) : "s"(p0), "s"(p1) : "memory");
+}
+
+// which of the eight XCDs this wave runs on (diagnostics: workgroup -> XCD placement is observed, not promised)
+static __device__ __forceinline__ uint32_t mm_xcc_id()
+{
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xFu;
+}
+
 #endif
