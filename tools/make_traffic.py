@@ -16,7 +16,7 @@ from bench import kernel_source_hash  # noqa: E402  (bench.py refuses a file mea
 def load(path, prefixes):
     out = {}
     for row in csv.DictReader(open(path)):
-        k = row["kernel"]
+        k = row["kernel"].replace("void ", "")          # template instances are listed as "void kp_round<2048u>"
         if any(k.startswith(p) for p in prefixes):
             out[k] = (float(row["sum"]), int(row["dispatches"]))
     return out

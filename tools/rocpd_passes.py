@@ -15,8 +15,15 @@ def main(path, first, names):
     per = collections.defaultdict(list)
     for n, s, d in seq:
         per[n.split("(")[0]].append(d / 1000.0)
-    for k in names:
+    for k in names:                      # a name also stands for its template instances ("void kp_round<2048u>")
         v = per.get(k, [])
+        if not v:
+            for full in sorted(per):
+                if full.replace("void ", "").split("<")[0] == k:
+                    print("%s,%d,sum_us=%.0f,avg_us=%.1f" % (full.replace("void ", ""), len(per[full]), sum(per[full]),
+                                                              sum(per[full]) / len(per[full])))
+            merged = [(s, n.split("(")[0], d) for n, s, d in seq if n.split("(")[0].replace("void ", "").split("<")[0] == k]
+            v = [d / 1000.0 for s, n, d in sorted(merged)]
         print("%s,%d,sum_us=%.0f,first10=%s,every10th=%s" % (k, len(v), sum(v), [round(x) for x in v[:10]],
                                                           [round(x) for x in v[10::10]]))
     t0 = seq[0][1]
