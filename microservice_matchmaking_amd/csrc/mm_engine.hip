@@ -922,6 +922,7 @@ struct mm_engine {
     bool pair_debug;           // MM_PAIR_DEBUG=1: print the pair path's diagnostics per tick
     uint32_t pair_tune;        // MM_PAIR_TUNE: PairParams.tune
     bool pair_tile_fixed;      // MM_PAIR_TILE=max: every batch with the largest tile length (A/B)
+    uint32_t pair_tiles_max;   // MM_PAIR_TILES: tiles of the longest chain a batch may have before the next larger tile length is taken
     unsigned long long live_upper;   // upper bound of queued players (grid sizing)
     // team path (mm_team.inc): shares the pair path's arrays, plus
     TeamChain* d_tchains;
@@ -1184,6 +1185,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
             const char* ptl = getenv("MM_PAIR_TILE");
             e->pair_tile_fixed = ptl && ptl[0] == 'm';
+            const char* ptm = getenv("MM_PAIR_TILES");
+            e->pair_tiles_max = ptm && atoi(ptm) > 0 ? (uint32_t)atoi(ptm) : PK_TILES_MAX;
             const char* pf = getenv("MM_PAIR_FUSED");
             e->pair_fused = !(pf && pf[0] == '0');
             e->round_ctr = 0;
@@ -1584,10 +1587,9 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             // walk costs one dependent load per tile, everything else is proportional to the tile); the
             // three-launch form of a round (MM_PAIR_FUSED=0) stays with the largest
             uint32_t tp = PK_TMAX;
-            if (e->pair_fused && !e->pair_tile_fixed) {
-                if ((longest + PK_TMAX / 4u - 1u) / (PK_TMAX / 4u) <= PK_TILES_MAX) tp = PK_TMAX / 4u;
-                else if ((longest + PK_TMAX / 2u - 1u) / (PK_TMAX / 2u) <= PK_TILES_MAX) tp = PK_TMAX / 2u;
-            }
+            if (e->pair_fused && !e->pair_tile_fixed)
+                for (uint32_t cand = PK_TMAX / 4u; cand < PK_TMAX; cand <<= 1)    // (an eighth was measured: slower, the fixed cost of a round takes over)
+                    if ((longest + cand - 1u) / cand <= e->pair_tiles_max) { tp = cand; break; }
             tiles = (longest + tp - 1u) / tp;
 #define TILE_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                                              \
     do {                                                                                                                   \
@@ -1838,6 +1840,10 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                             hp[g].tm[1] / nr, hp[g].tm[2] / nr, hp[g].tm[3] / nr, hp[g].tm[4] / nr);
             }
         if (e->pair_tune & 0x2000u) {
+            unsigned long long tested = 0, algo = 0;
+            for (uint32_t g = 0; g < G; ++g) { tested += hp[g].tested; algo += hp[g].pairs; }
+            fprintf(stderr, "[mm-pair] predicate tests the kernels physically performed (next[] build, repairs, head scans, LDS-resident walk): %llu = %.2f x the %llu pair evaluations of the reference algorithm\n",
+                    tested, algo ? (double)tested / (double)algo : 0.0, algo);
             std::vector<uint32_t> xc(e->pk_max_tiles);
             HIPCHK(e, hipMemcpy(xc.data(), e->d_pk_tilectl + ((size_t)TC_DISP * G + 0) * e->pk_max_tiles,
                                 e->pk_max_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
