@@ -1191,7 +1191,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_fused = !(pf && pf[0] == '0');
             e->round_ctr = 0;
             const char* pb = getenv("MM_PAIR_BATCH");
-            e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 32u;
+            e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 48u;   // 16 / 32 / 48 / 64 measured: 48 by 1-2 %
             if (e->pair_batch < 1u) e->pair_batch = 1u;
             const char* tb = getenv("MM_TEAM_BATCH");
             e->team_batch = tb ? (uint32_t)strtoul(tb, NULL, 0) : 16u;

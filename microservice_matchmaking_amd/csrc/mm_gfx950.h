@@ -9,12 +9,21 @@
 // keep a value alive in a vector register (a load whose result is only wanted in the cache)
 #define TW_SINK(v) asm volatile("" ::"v"(v))
 
+// a wave-uniform address the compiler may hold in vector registers: into scalar registers
+static __device__ __forceinline__ const uint32_t* tw_sptr(const uint32_t* p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const uint32_t*)(((unsigned long long)hi << 32) | lo);
+}
+
 // one dword through the scalar cache (K$ -> L2): the dependent load of a pointer chase whose
 // address is wave-uniform
 static __device__ __forceinline__ uint32_t tw_sload(const uint32_t* p)
 {
     uint32_t v;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tw_sptr(p)) : "memory");
     return v;
 }
 
@@ -23,7 +32,7 @@ static __device__ __forceinline__ uint32_t tw_sload(const uint32_t* p)
 static __device__ __forceinline__ void tw_sload2(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1)
 {
     asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(v0), "=&s"(v1) : "s"(p0), "s"(p1) : "memory");
+                 : "=&s"(v0), "=&s"(v1) : "s"(tw_sptr(p0)), "s"(tw_sptr(p1)) : "memory");
 }
 
 // which of the eight XCDs this wave runs on (diagnostics: workgroup -> XCD placement is observed, not promised)
