@@ -1577,7 +1577,11 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             uint32_t longest = 0;
             for (uint32_t g = 0; g < G; ++g) {
                 const PairChain& pc = e->h_pchains[g];
+                P.bm[g] = 0;
+                P.bbuf[g] = 0;
                 if (!pc.fast || pc.stage != PS_TILED) continue;
+                P.bm[g] = pc.m;                       // constant until the next compaction, i.e. for the whole batch
+                P.bbuf[g] = (uint8_t)pc.buf;
                 tiled = true;
                 compact |= pc.want_compact != 0;
                 longest = pc.m > longest ? pc.m : longest;
