@@ -19,11 +19,11 @@ static __device__ __forceinline__ const uint32_t* tw_sptr(const uint32_t* p)
 }
 
 // one dword through the scalar cache (K$ -> L2): the dependent load of a pointer chase whose
-// address is wave-uniform
+// address is wave-uniform AND held in scalar registers (the hot loops; tw_sload_v takes any)
 static __device__ __forceinline__ uint32_t tw_sload(const uint32_t* p)
 {
     uint32_t v;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tw_sptr(p)) : "memory");
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
 
@@ -32,7 +32,14 @@ static __device__ __forceinline__ uint32_t tw_sload(const uint32_t* p)
 static __device__ __forceinline__ void tw_sload2(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1)
 {
     asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(v0), "=&s"(v1) : "s"(tw_sptr(p0)), "s"(tw_sptr(p1)) : "memory");
+                 : "=&s"(v0), "=&s"(v1) : "s"(p0), "s"(p1) : "memory");
+}
+
+// the same for addresses that are wave-uniform but that the compiler holds in vector registers
+static __device__ __forceinline__ uint32_t tw_sload_v(const uint32_t* p) { return tw_sload(tw_sptr(p)); }
+static __device__ __forceinline__ void tw_sload2_v(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1)
+{
+    tw_sload2(tw_sptr(p0), tw_sptr(p1), v0, v1);
 }
 
 // which of the eight XCDs this wave runs on (diagnostics: workgroup -> XCD placement is observed, not promised)

@@ -5,5 +5,7 @@
 #define TW_SINK(v) asm volatile("" ::"r"(v))
 static inline uint32_t tw_sload(const uint32_t* p) { return *p; }
 static inline void tw_sload2(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) { v0 = *p0; v1 = *p1; }
+static inline uint32_t tw_sload_v(const uint32_t* p) { return *p; }
+static inline void tw_sload2_v(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) { v0 = *p0; v1 = *p1; }
 static inline uint32_t mm_xcc_id() { return 0; }
 #endif
