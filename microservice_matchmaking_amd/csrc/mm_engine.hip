@@ -929,6 +929,9 @@ struct mm_engine {
     TeamChain* h_tchains;      // pinned
     uint32_t* d_tk_chunk;      // [group][role][tk_chunk_stride]
     uint32_t* d_tk_fv2;        // [group][pk_stride] F o F of the team walk's first passes
+    uint32_t* d_tk_fpos;       // [group][pk_stride] kt_f's record of the lobby a position opens: its last member
+    uint16_t* d_tk_memb;       // [group][pk_stride][tk_memb] ... and all of them (team modes only)
+    uint32_t tk_memb;          // largest lobby of a team mode, less the anchor
     uint32_t team_f2;          // MM_TEAM_F2: passes of a tick that compose F with itself (0 = never)
     uint32_t tk_chunk_stride;
     uint32_t team_batch;       // MM_TEAM_BATCH: passes launched per host look at the chains
@@ -1123,6 +1126,8 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_tchains);
     (void)hipFree(e->d_tk_chunk);
     (void)hipFree(e->d_tk_fv2);
+    (void)hipFree(e->d_tk_fpos);
+    (void)hipFree(e->d_tk_memb);
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(e->d_pk_key[b]); (void)hipFree(e->d_pk_oidx[b]);
         (void)hipFree(e->d_pk_nx16[b]); (void)hipFree(e->d_pk_bits[b]);
@@ -1204,6 +1209,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* tcap = getenv("MM_TEAM_CAP");
             e->team_cap = tcap ? (uint32_t)strtoul(tcap, NULL, 0) : TT_SCAN_CAP;
             if (e->team_cap < 1u) e->team_cap = 1u;
+            if (e->team_cap > 4096u) e->team_cap = 4096u;      // kt_f notes members as 13-bit sub-queue offsets (TF_REL_BITS)
         }
         const size_t cap = cfg->capacity;
     #define CREATE_CHK(call)                                                 \
@@ -1267,6 +1273,15 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             CREATE_CHK(hipMalloc((void**)&e->d_tchains, cfg->n_groups * sizeof(TeamChain)));
             CREATE_CHK(hipMalloc((void**)&e->d_tk_chunk, (size_t)cfg->n_groups * MM_MAX_ROLES * e->tk_chunk_stride * sizeof(uint32_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_tk_fv2, gc * sizeof(uint32_t)));
+            e->tk_memb = 0;
+            for (uint32_t k = 0; k < cfg->n_modes; ++k) {
+                const uint32_t L = cfg->modes[k].teams * cfg->modes[k].team_size;
+                if (L > 2u && L - 1u > e->tk_memb) e->tk_memb = L - 1u;
+            }
+            if (e->tk_memb) {
+                CREATE_CHK(hipMalloc((void**)&e->d_tk_fpos, gc * sizeof(uint32_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_tk_memb, gc * e->tk_memb * sizeof(uint16_t)));
+            }
             CREATE_CHK(hipHostMalloc((void**)&e->h_tchains, cfg->n_groups * sizeof(TeamChain), hipHostMallocDefault));
             CREATE_CHK(hipMemsetAsync(e->d_tchains, 0, cfg->n_groups * sizeof(TeamChain), e->stream));
         }
@@ -1686,6 +1701,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     P.blkbase = e->d_pk_oidx[1];
     P.chunk = e->d_tk_chunk;
     P.fv2 = e->d_tk_fv2;
+    P.fpos = e->d_tk_fpos;
+    P.memb = e->d_tk_memb;
     P.use_f2 = 0;
     P.out_slots = e->d_out_slots;
     P.out_score = e->d_out_score;
@@ -1741,9 +1758,9 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     HIPCHK(e, hipGetLastError());
     if (e->pair_debug)
         for (uint32_t g = 0; g < G; ++g)
-            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | kt_f chunk 1 cycles/pass: stage %u scan(wave 0) %u scan(workgroup) %u tail %u | F values written %u, changed after the first pass %u\n", g, e->h_tchains[g].fast,
+            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x (raw %08x) | kt_f chunk 1 cycles/pass: stage %u scan(wave 0) %u scan(workgroup) %u tail %u | F values written %u, changed after the first pass %u\n", g, e->h_tchains[g].fast,
                     e->h_tchains[g].m, e->h_tchains[g].passes, e->h_tchains[g].n_out, e->h_tchains[g].qlen,
-                    e->h_tchains[g].dbg[6] & 1u, (e->h_tchains[g].dbg[6] >> 1) & 1u, (e->h_tchains[g].dbg[6] >> 2) & 1u, e->h_tchains[g].dbg[7],
+                    e->h_tchains[g].dbg[6] & 1u, (e->h_tchains[g].dbg[6] >> 1) & 1u, (e->h_tchains[g].dbg[6] >> 2) & 1u, e->h_tchains[g].dbg[7], e->h_tchains[g].dbg[6],
                     e->h_tchains[g].dbg[0] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[1] / (e->h_tchains[g].passes + 1u),
                     e->h_tchains[g].dbg[2] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[3] / (e->h_tchains[g].passes + 1u),
                     e->h_tchains[g].dbg[5], e->h_tchains[g].dbg[4]);
