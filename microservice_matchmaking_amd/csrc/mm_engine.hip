@@ -878,6 +878,7 @@ struct mm_engine {
     uint32_t n_chains;
     hipStream_t stream;
     hipEvent_t ev[4];
+    hipEvent_t ev_grp[MM_MAX_GROUPS];   // a group's match list has reached the host
     int last_hip;
     // device
     int32_t* d_q_rating;
@@ -1147,6 +1148,8 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (int i = 0; i < 4; ++i)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (uint32_t i = 0; i < MM_MAX_GROUPS; ++i)
+        if (e->ev_grp[i]) (void)hipEventDestroy(e->ev_grp[i]);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1228,6 +1231,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         }
         CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         for (int i = 0; i < 4; ++i) CREATE_CHK(hipEventCreate(&e->ev[i]));
+        for (uint32_t i = 0; i < cfg->n_groups; ++i) CREATE_CHK(hipEventCreate(&e->ev_grp[i]));
         CREATE_CHK(hipMalloc((void**)&e->d_q_rating, e->n_chains * cap * sizeof(int32_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_q_cons, e->n_chains * cap * sizeof(uint32_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_q_slot, e->n_chains * cap * sizeof(uint32_t)));
@@ -1758,12 +1762,15 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     HIPCHK(e, hipGetLastError());
     if (e->pair_debug)
         for (uint32_t g = 0; g < G; ++g)
-            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x (raw %08x) | kt_f chunk 1 cycles/pass: stage %u scan(wave 0) %u scan(workgroup) %u tail %u | F values written %u, changed after the first pass %u\n", g, e->h_tchains[g].fast,
-                    e->h_tchains[g].m, e->h_tchains[g].passes, e->h_tchains[g].n_out, e->h_tchains[g].qlen,
-                    e->h_tchains[g].dbg[6] & 1u, (e->h_tchains[g].dbg[6] >> 1) & 1u, (e->h_tchains[g].dbg[6] >> 2) & 1u, e->h_tchains[g].dbg[7], e->h_tchains[g].dbg[6],
-                    e->h_tchains[g].dbg[0] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[1] / (e->h_tchains[g].passes + 1u),
-                    e->h_tchains[g].dbg[2] / (e->h_tchains[g].passes + 1u), e->h_tchains[g].dbg[3] / (e->h_tchains[g].passes + 1u),
-                    e->h_tchains[g].dbg[5], e->h_tchains[g].dbg[4]);
+        {
+            const TeamChain& t = e->h_tchains[g];
+            const uint32_t np = t.passes + 1u;
+            fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | "
+                    "kt_f chunk 1, cycles per pass: set-up %u, windows + step A %u, scans %u, long scans %u, lobbies %u, step C %u; anchors looked up per pass %u | "
+                    "F values written %u, changed after the first pass %u\n", g, t.fast, t.m, t.passes, t.n_out, t.qlen,
+                    t.dbg[6] & 1u, (t.dbg[6] >> 1) & 1u, (t.dbg[6] >> 2) & 1u, t.dbg[7],
+                    t.tmk[0] / np, t.tmk[1] / np, t.tmk[2] / np, t.tmk[3] / np, t.tmk[4] / np, t.tmk[5] / np, t.dbg[2] / np, t.dbg[5], t.dbg[4]);
+        }
     return MM_OK;
 }
 
@@ -1910,27 +1917,43 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     if (errf) return MM_ERR_INTERNAL;
     if ((size_t)total * M.L > (size_t)cfg.capacity + (size_t)MM_MAX_LOBBY * G) return MM_ERR_INTERNAL;
     e->r_group.resize(total);
+    // The match list, group-major emission order.  The slots go first, group by group, each followed by
+    // an event: while the rest is still on its way the host already does its part for the groups that
+    // arrived — ActiveUser.remove_user for the matched players (game-lobby/worker.ex:73-103).
     uint32_t k = 0;
-    for (uint32_t g = 0; g < G; ++g) {   // group-major emission order
+    for (uint32_t g = 0; g < G; ++g) {
         const uint32_t ng = e->h_chains[mode * G + g].n_out;
         if (!ng) continue;
         HIPCHK(e, hipMemcpyAsync(&e->h_rslots[(size_t)k * M.L], e->d_out_slots + (size_t)g * e->out_slot_stride,
                                  (size_t)ng * M.L * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipEventRecord(e->ev_grp[g], e->stream));
+        k += ng;
+    }
+    k = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t ng = e->h_chains[mode * G + g].n_out;
+        if (!ng) continue;
         HIPCHK(e, hipMemcpyAsync(&e->h_rscore[k], e->d_out_score + (size_t)g * e->out_rec_stride, ng * sizeof(float),
                                  hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipMemcpyAsync(&e->h_rpass[k], e->d_out_pass + (size_t)g * e->out_rec_stride, ng * sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, e->stream));
-        for (uint32_t i = 0; i < ng; ++i) e->r_group[k + i] = g;
         k += ng;
     }
     const uint32_t nrel = e->h_counters[0];
     e->r_released.resize(nrel);
     if (nrel)
         HIPCHK(e, hipMemcpyAsync(e->r_released.data(), e->d_released, nrel * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    k = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t ng = e->h_chains[mode * G + g].n_out;
+        if (!ng) continue;
+        for (uint32_t i = 0; i < ng; ++i) e->r_group[k + i] = g;
+        HIPCHK(e, hipEventSynchronize(e->ev_grp[g]));
+        for (size_t i = (size_t)k * M.L, ns = (size_t)(k + ng) * M.L; i < ns; ++i) e->h_state[e->h_rslots[i]] = MM_ST_FREE;
+        k += ng;
+    }
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    // ActiveUser.remove_user for matched players (game-lobby/worker.ex:73-103) and the
-    // slots the liveness filter released
-    for (size_t i = 0, ns = (size_t)total * M.L; i < ns; ++i) e->h_state[e->h_rslots[i]] = MM_ST_FREE;
+    // ... and the slots the liveness filter released
     for (uint32_t i = 0; i < nrel; ++i) e->h_state[e->r_released[i]] = MM_ST_FREE;
     e->cancel_pending = e->cancel_pending >= nrel ? e->cancel_pending - nrel : 0;
     {
