@@ -267,6 +267,24 @@ def test_gpu_team_scan_horizon(gpu_cls, oracle_cls, monkeypatch, cap):
         assert_same_state(a, b, cfg)
 
 
+def test_gpu_team_members_beyond_the_record(gpu_cls, oracle_cls):
+    """kt_f keeps every anchor's lobby on record as 16-bit distances from the anchor.  Here the players of
+    the second role all queue 70 000 positions behind the first anchors, so no lobby fits the record for a
+    lobby fits the record in any of the 500 passes (those anchors are looked up again every pass): a pass
+    seats one such lobby, the next anchor's stays open and is filled from the head of the queue in the pass
+    after.  Same lobbies, same order."""
+    n0, n1 = 70000, 2000
+    cfg = make_config([mode_team(2, 2, 5000, (1, 1))], groups=[(0, 5000, "all")], capacity=1 << 17)
+    rating = np.full(n0 + n1, 2500, np.int32)
+    cons = cons_make(0, 0, 0, np.concatenate([np.zeros(n0, np.uint32), np.ones(n1, np.uint32)]))
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+        ma, mb = a.tick(0), b.tick(0)
+        assert len(ma) == n1 // 2 and ma.stats["passes_max"] >= n1 // 4
+        assert_same_tick(ma, mb, "far members", SCORE_TOL)
+        assert_same_state(a, b, cfg)
+
+
 def test_gpu_restart_from_a_snapshot(gpu_cls, oracle_cls):
     """mm_snapshot / mm_restore on the device: the engine is destroyed and rebuilt from its
     snapshot three times (cancels pending across two of them); pools large enough for the pair
