@@ -932,6 +932,10 @@ struct mm_engine {
     uint32_t* d_tk_fv2;        // [group][pk_stride] F o F of the team walk's first passes
     uint32_t* d_tk_fpos;       // [group][pk_stride] kt_f's record of the lobby a position opens: its last member
     uint16_t* d_tk_memb;       // [group][pk_stride][tk_memb] ... and all of them (team modes only)
+    uint32_t* d_tk_bitsB;      // [group][pk_bits_stride] the queue bitmap when kt_build last ran
+    uint32_t* d_tk_chunkB;     // [group][role][tk_chunk_stride] chunk populations when kt_build last ran
+    uint32_t* d_tk_sqi;        // [group][pk_stride] position -> sub-queue entry
+    uint32_t team_rebuild;     // MM_TEAM_REBUILD: kt_build runs in the first two passes of a tick and every this many after
     uint32_t tk_memb;          // largest lobby of a team mode, less the anchor
     uint32_t team_f2;          // MM_TEAM_F2: passes of a tick that compose F with itself (0 = never)
     uint32_t tk_chunk_stride;
@@ -1129,6 +1133,9 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_tk_fv2);
     (void)hipFree(e->d_tk_fpos);
     (void)hipFree(e->d_tk_memb);
+    (void)hipFree(e->d_tk_bitsB);
+    (void)hipFree(e->d_tk_chunkB);
+    (void)hipFree(e->d_tk_sqi);
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(e->d_pk_key[b]); (void)hipFree(e->d_pk_oidx[b]);
         (void)hipFree(e->d_pk_nx16[b]); (void)hipFree(e->d_pk_bits[b]);
@@ -1209,6 +1216,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             if (e->team_batch < 1u) e->team_batch = 1u;
             const char* tf2 = getenv("MM_TEAM_F2");
             e->team_f2 = tf2 ? (uint32_t)strtoul(tf2, NULL, 0) : 32u;   // 24 / 40 measured within 0.1 ms of each other
+            const char* trb = getenv("MM_TEAM_REBUILD");
+            e->team_rebuild = trb ? (uint32_t)strtoul(trb, NULL, 0) : 8u;   // 4 / 6 / 8 measured within 0.1 ms of each other, 16: +0.9 ms, every pass: +1.4 ms
+            if (e->team_rebuild < 1u) e->team_rebuild = 1u;
             const char* tcap = getenv("MM_TEAM_CAP");
             e->team_cap = tcap ? (uint32_t)strtoul(tcap, NULL, 0) : TT_SCAN_CAP;
             if (e->team_cap < 1u) e->team_cap = 1u;
@@ -1285,6 +1295,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             if (e->tk_memb) {
                 CREATE_CHK(hipMalloc((void**)&e->d_tk_fpos, gc * sizeof(uint32_t)));
                 CREATE_CHK(hipMalloc((void**)&e->d_tk_memb, gc * e->tk_memb * sizeof(uint16_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_tk_bitsB, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_tk_chunkB, (size_t)cfg->n_groups * MM_MAX_ROLES * e->tk_chunk_stride * sizeof(uint32_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_tk_sqi, gc * sizeof(uint32_t)));
             }
             CREATE_CHK(hipHostMalloc((void**)&e->h_tchains, cfg->n_groups * sizeof(TeamChain), hipHostMallocDefault));
             CREATE_CHK(hipMemsetAsync(e->d_tchains, 0, cfg->n_groups * sizeof(TeamChain), e->stream));
@@ -1707,6 +1720,9 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     P.fv2 = e->d_tk_fv2;
     P.fpos = e->d_tk_fpos;
     P.memb = e->d_tk_memb;
+    P.bitsB = e->d_tk_bitsB;
+    P.chunkB = e->d_tk_chunkB;
+    P.sqi = e->d_tk_sqi;
     P.use_f2 = 0;
     P.out_slots = e->d_out_slots;
     P.out_score = e->d_out_score;
@@ -1731,7 +1747,11 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         for (uint32_t b = 0; b < e->team_batch; ++b) {
             // the first passes of a tick emit hundreds of lobbies each: the chase takes them two at a time (kt_f2)
             P.use_f2 = guard * e->team_batch + b < e->team_f2 ? 1u : 0u;
-            hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+            // the role sub-queues are rebuilt in the first two passes (a head that sat out the first one is back in
+            // the second) and every team_rebuild passes after; in between, players that leave are tombstones in them
+            const uint32_t pass = guard * e->team_batch + b;
+            if (pass < 2u || pass % e->team_rebuild == 0u)
+                hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
             hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
             if (P.use_f2) hipLaunchKernelGGL(kt_f2, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
             if (P.use_f2) hipLaunchKernelGGL(kt_chase<1>, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
