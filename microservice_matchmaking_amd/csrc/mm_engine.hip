@@ -1786,7 +1786,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             const TeamChain& t = e->h_tchains[g];
             const uint32_t np = t.passes + 1u;
             fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | "
-                    "kt_f chunk 1, cycles per pass: set-up %u, windows + step A %u, scans %u, long scans %u, lobbies %u, step C %u; anchors looked up per pass %u | "
+                    "kt_f, the middle chunk, cycles per pass: set-up %u, windows + step A %u, scans %u, long scans %u, lobbies %u, step C %u; anchors looked up per pass %u | "
                     "F values written %u, changed after the first pass %u\n", g, t.fast, t.m, t.passes, t.n_out, t.qlen,
                     t.dbg[6] & 1u, (t.dbg[6] >> 1) & 1u, (t.dbg[6] >> 2) & 1u, t.dbg[7],
                     t.tmk[0] / np, t.tmk[1] / np, t.tmk[2] / np, t.tmk[3] / np, t.tmk[4] / np, t.tmk[5] / np, t.dbg[2] / np, t.dbg[5], t.dbg[4]);

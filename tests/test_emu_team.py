@@ -67,6 +67,16 @@ def test_team_narrow_window_scan_cap(oracle_cls):
                  lo=0, hi=1400, weights=W5) > 10
 
 
+@pytest.mark.parametrize("every", ["1", "3", "100000"])
+def test_team_rebuild_cadence(oracle_cls, monkeypatch, every):
+    """MM_TEAM_REBUILD: role sub-queues rebuilt in every pass, every third, or only in the first two passes of
+    a tick — in between, players that leave are tombstones in them and the ranks count the entries of the
+    last rebuild.  Same lobbies (stored lobbies, several ticks)."""
+    monkeypatch.setenv("MM_TEAM_REBUILD", every)
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 60, (1, 1, 1, 1, 1)), 1500, seed=8, n_ticks=3,
+                 lo=0, hi=1400, weights=W5) > 10
+
+
 def test_team_cancel_ticks(oracle_cls):
     """Ticks with pending cancels on the team path: k_purge, then kt_init judges the head against
     the stale lobby and filters it (the head sits out the first pass or is seated), and a stored

@@ -267,6 +267,21 @@ def test_gpu_team_scan_horizon(gpu_cls, oracle_cls, monkeypatch, cap):
         assert_same_state(a, b, cfg)
 
 
+@pytest.mark.parametrize("every", [1, 3, 100000])
+def test_gpu_team_rebuild_cadence(gpu_cls, oracle_cls, monkeypatch, every):
+    """MM_TEAM_REBUILD: the role sub-queues rebuilt in every pass (no tombstones at all), every third, or only
+    in the first two passes of a tick (everybody who leaves afterwards is a tombstone until the tick ends).
+    Two ticks with arrivals in between.  Same lobbies."""
+    monkeypatch.setenv("MM_TEAM_REBUILD", str(every))
+    cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 18)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        for k, n in enumerate([150000, 40000]):
+            rating, cons = make_pool(n, seed=21 + k, role_weights=ROLE_WEIGHTS_5V5)
+            assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+            assert_same_tick(a.tick(0), b.tick(0), "rebuild every %d, tick %d" % (every, k), SCORE_TOL)
+            assert_same_state(a, b, cfg)
+
+
 def test_gpu_team_members_beyond_the_record(gpu_cls, oracle_cls):
     """kt_f keeps every anchor's lobby on record as 16-bit distances from the anchor.  Here the players of
     the second role all queue 70 000 positions behind the first anchors, so no lobby fits the record for a
