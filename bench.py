@@ -127,7 +127,7 @@ def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passe
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120, help="default: a timed region of about 2 s at N=1")
+    ap.add_argument("--steps", type=int, default=180, help="default: a timed region of a good 2 s at N=1 (12 ms per step)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--players", type=int, default=None,
                     help="pool size; default 1,000,000 at N=1 (cfg-2) and 10,000,000 at N>1 (cfg-4, one shared pool)")
