@@ -137,6 +137,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency legs")
+    ap.add_argument("--no-boundary", action="store_true",
+                    help="skip the kernel-boundary micro-measurement (torch add kernels; tools/collect_profiles.sh "
+                         "passes this so that the profiled command holds the engine's kernels only)")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3 leg (BASELINE configs[2] beside the main line)")
+    ap.add_argument("--cfg3-steps", type=int, default=12)
+    ap.add_argument("--no-prediction", action="store_true",
+                    help="skip sharding_prediction (every rank's share of the 10M pool run alone on this GPU)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (weak_scaling at N>1, shared_pool_n1 and concurrent_pools at N=1)")
     ap.add_argument("--concurrent-pools", type=int, default=2,
@@ -266,10 +273,25 @@ def concurrent_pools(make_engine, pools, steps, make_inputs):
                     "(measured sweet spot: 2 pools, profiles/r02_concurrent_pools_*.json)"}
 
 
-def stream_leg(search, dist, rank, world, qps, seconds, tick_ms, label, seed=77, mode_weights=None, role_weights=None):
+def tick_cost_windows(cost, tick_ms, window_s=10.0):
+    """Per-tick host+device cost of a stream, summarised per window of the stream's own clock."""
+    cost = np.asarray(cost, dtype=np.float64) * 1e3
+    per = max(1, int(round(window_s * 1000.0 / tick_ms)))
+    out = []
+    for k in range(0, len(cost), per):
+        c = cost[k:k + per]
+        out.append({"from_s": k * tick_ms * 1e-3, "p50": float(np.percentile(c, 50)), "p99": float(np.percentile(c, 99)),
+                    "max": float(c.max())})
+    return out
+
+
+def stream_leg(search, dist, rank, world, qps, seconds, tick_ms, label, key_label, seed=77, mode_weights=None,
+               role_weights=None):
     """Second half of BASELINE.json's metric: match latency at a fixed enqueue rate
     (microservice_matchmaking_amd/stream.py).  Every rank sees the whole stream and keeps its
-    chains; rank 0 gathers the latencies of all ranks."""
+    chains; rank 0 gathers the latencies of all ranks.  The stream is tick-count driven, so what it
+    emits is deterministic: the union digest, the matched players and the backlog are checked against
+    the oracle's run of the same schedule (tests/golden/shared_pool_digests.json)."""
     from microservice_matchmaking_amd.sharding import union_digest
     from microservice_matchmaking_amd.stream import latency_summary, run_stream, stream_batch, stream_schedule
     n_modes = int(search.cfg.n_modes)
@@ -284,7 +306,8 @@ def stream_leg(search, dist, rank, world, qps, seconds, tick_ms, label, seed=77,
     res = run_stream(search, sched, mode_weights=mode_weights, role_weights=role_weights, realtime=True)
     mine = {c: d for c, d in res["digests"].items() if search.sharding.chain_owner[c] == rank}
     part = {"real": res["real"], "floor": res["floor"], "matched": res["matched"], "elapsed": res["elapsed"],
-            "tick_cost": res["tick_cost"], "depth": [d.tolist() for d in res["depth"]], "digests": mine}
+            "tick_cost": res["tick_cost"], "depth": [d.tolist() for d in res["depth"]], "digests": mine,
+            "full_at_s": res.get("full_at_s")}
     parts = [part]
     if dist is not None:
         parts = [None] * world
@@ -300,22 +323,37 @@ def stream_leg(search, dist, rank, world, qps, seconds, tick_ms, label, seed=77,
     real = np.concatenate([cat("real", md) for md in range(n_modes)])
     floor = np.concatenate([cat("floor", md) for md in range(n_modes)])
     elapsed = max(p["elapsed"] for p in parts)
-    cost = np.concatenate([p["tick_cost"] for p in parts])
+    cost = np.max(np.stack([np.asarray(p["tick_cost"]) for p in parts]), axis=0) if len({len(p["tick_cost"]) for p in parts}) == 1 \
+        else np.concatenate([p["tick_cost"] for p in parts])
     digests = {}
     for p in parts:
         digests.update(p["digests"])
-    out = {"enqueue_qps": qps, "tick_ms": tick_ms, "seconds": seconds, "mode": label, "ranks": world}
+    matched = int(sum(p["matched"] for p in parts))
+    got = union_digest(digests)
+    want = expected_digest(stream_key(key_label, qps, seconds, tick_ms, seed))
+    out = {"enqueue_qps": qps, "tick_ms": tick_ms, "seconds": seconds, "mode": label, "ranks": world,
+           "capacity": int(search.cfg.capacity)}
     out.update(latency_summary(real, floor))
+    backlog = [int(s["backlog_players"]) for s in per_mode]
     out.update({
-        "matched_players_per_s": sum(p["matched"] for p in parts) / elapsed,
-        "tick_cost_ms_mean": float(np.mean(cost) * 1e3), "tick_cost_ms_p99": float(np.percentile(cost, 99) * 1e3),
-        "backlog_players": int(sum(s["backlog_players"] for s in per_mode)),
+        "matched_players_per_s": matched / elapsed,
+        "tick_cost_ms_mean": float(np.mean(cost) * 1e3), "tick_cost_ms_p50": float(np.percentile(cost, 50) * 1e3),
+        "tick_cost_ms_p99": float(np.percentile(cost, 99) * 1e3), "tick_cost_ms_max": float(np.max(cost) * 1e3),
+        "tick_cost_ms_by_10s": tick_cost_windows(cost, tick_ms),
+        "backlog_players": int(sum(backlog)),
         "kept_up": bool(elapsed < seconds * 1.05),
-        "emission_digest": union_digest(digests),
+        "elapsed_s": elapsed,
+        "capacity_exhausted_at_s": next((p["full_at_s"] for p in parts if p["full_at_s"] is not None), None),
+        "emission_digest": got,
+        "oracle_digest": want["digest"] if want else None,
+        "ok": (got == want["digest"] and matched == want["matched"]
+               and backlog == [int(sum(b)) for b in want["backlog"]]) if want else None,
+        "oracle_matched": want["matched"] if want else None,
         "note": "floor_* = end of the tick period in which the player was matched minus its arrival: the wait for "
                 "fitting partners to ARRIVE (reference behaviour, docs/MATCH_CHECK.md section 4: a chain whose "
                 "anchor nobody fits waits for arrivals), what an engine with a free tick would give; "
-                "engine_added = real - floor"})
+                "engine_added = real - floor; ok = emission digest, matched players and backlog per mode equal the "
+                "CPU oracle's run of the same tick schedule (committed digest; None: no digest for this schedule)"})
     if n_modes > 1:
         out["per_mode"] = per_mode
     return out
@@ -323,6 +361,29 @@ def stream_leg(search, dist, rank, world, qps, seconds, tick_ms, label, seed=77,
 
 def workload_key(mode, players, window, dist_name, seed=1):
     return "%s/%d/w%d/%s/seed%d" % (mode, players, window, dist_name, seed)
+
+
+def stream_key(label, qps, seconds, tick_ms, seed=77):
+    """Key of a stream leg in tests/golden/shared_pool_digests.json (label: "1v1" | "mixed")."""
+    return "stream/%s/qps%d/s%g/tick%g/seed%d" % (label, qps, seconds, tick_ms, seed)
+
+
+def stream_capacity(qps, seconds):
+    """Slot ring of a stream engine.  A stream's pool is what has not been matched yet; cfg-5's 5v5 half has no
+    steady state (the role weights cap its match rate at half of its arrivals), so the pool
+    grows by about 15 % of the arrivals: sized at 30 % of everything that arrives, at least 1M slots."""
+    cap = 1 << 20
+    while cap < 0.3 * qps * seconds:
+        cap <<= 1
+    return cap
+
+
+def predict_speedup(n1_step_ms, per_rank_ms):
+    """Strong scaling of ONE pool sharded by chain: the pool's step on one GPU over the slowest rank's step
+    (each rank's figure = ITS chains together on one GPU, overlapped as measured).  Not the load share: one GPU
+    already runs all chains concurrently, so the heaviest chain's time bounds every N."""
+    slow = max([float(t) for t in per_rank_ms] or [0.0])
+    return (float(n1_step_ms) / slow) if slow > 0 else None
 
 
 def expected_digest(key):
@@ -352,18 +413,18 @@ def main():
                                                        tick_digests, union_digest)
     from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5, make_pool
 
-    if args.mode == "1v1":
-        modes = [mode_1v1(window=args.window, region_filter=True)]
-        pool_kw = {}
-        bytes_per_pair = BYTES_PER_PAIR
-        window = args.window
-        describe = lambda n: "1v1, %d players, +-%d rating + region filter (8 regions), %s ratings" % (n, args.window, args.dist)
-    else:
-        modes = [mode_team(5, 2, 50, (1, 1, 1, 1, 1))]
-        pool_kw = {"role_weights": ROLE_WEIGHTS_5V5}
-        bytes_per_pair = 12
-        window = 50
-        describe = lambda n: "5v5 team balance, %d players, +-50 rating + 5 roles, %s ratings" % (n, args.dist)
+    def workload(mode):
+        if mode == "1v1":
+            return {"mode": "1v1", "modes": [mode_1v1(window=args.window, region_filter=True)], "pool_kw": {},
+                    "bytes_per_pair": BYTES_PER_PAIR, "window": args.window,
+                    "describe": lambda n: "1v1, %d players, +-%d rating + region filter (8 regions), %s ratings" % (
+                        n, args.window, args.dist)}
+        return {"mode": "5v5", "modes": [mode_team(5, 2, 50, (1, 1, 1, 1, 1))], "pool_kw": {"role_weights": ROLE_WEIGHTS_5V5},
+                "bytes_per_pair": 12, "window": 50,
+                "describe": lambda n: "5v5 team balance, %d players, +-50 rating + 5 roles, %s ratings" % (n, args.dist)}
+
+    wl = workload(args.mode)
+    describe = wl["describe"]
 
     def pow2(n):
         cap = 1
@@ -377,18 +438,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def shared_pool_run(n, w, r, steps, warmup, timing=True):
-        """One pool of n players, sharded over w ranks by chain; this process is rank r of them.
-        Returns (elapsed of the timed steps on this rank, last tick, per-step timers, my digests,
-        the sharding, players this rank holds).  The caller brackets it with fence()."""
-        rating, cons = make_pool(n, seed=1, dist=args.dist, **pool_kw)
+    pools = {}
+
+    def pool_of(w, n):
+        key = (w["mode"], n)
+        if key not in pools:
+            pools.clear()                                  # one pool at a time (10M players: 80 MB of host arrays)
+            pools[key] = make_pool(n, seed=1, dist=args.dist, **w["pool_kw"])
+        return pools[key]
+
+    def shared_pool_run(w, n, nranks, r, steps, warmup, timing=True, collective=True):
+        """One pool of n players, sharded over nranks by chain; this process plays rank r of them.
+        Returns (elapsed of the timed steps, last tick, per-step timers, my digests, the sharding, players
+        held, the pool).  collective=False: a single-process run (no barrier with the other ranks)."""
+        rating, cons = pool_of(w, n)
+        modes = w["modes"]
         cfg1 = make_config(modes, capacity=16, device=local_rank, timing=False)
-        sh = ChainSharding(1, cfg1.n_groups, w, chain_weights(cfg1, rating, cons)[0])
+        sh = ChainSharding(1, cfg1.n_groups, nranks, chain_weights(cfg1, rating, cons)[0])
         grp = rating_groups(cfg1, rating)
         idx = np.nonzero(sh.chain_owner[0][grp.astype(np.int64)] == r)[0]
         timers = {"walk": [], "bucket": [], "copy": []}
         digests, last = {}, None
         elapsed = 0.0
+        sync = fence if collective else torch.cuda.synchronize
         if idx.size:
             cfg = make_config(modes, capacity=pow2(idx.size), device=local_rank, timing=timing)
             d_rating = torch.from_numpy(rating[idx]).cuda()
@@ -401,7 +473,7 @@ def main():
                 return first, eng.tick(0), dict(eng.last_enqueue_stats)
             for _ in range(warmup):
                 step()
-        fence()
+        sync()
         t0 = time.perf_counter()
         if idx.size:
             for _ in range(steps):
@@ -411,7 +483,7 @@ def main():
                 timers["copy"].append(last.stats["copy_ms"])
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        fence()
+        sync()
         if idx.size:
             ids = idx[(last.slots.astype(np.int64) - first) % int(cfg.capacity)] if len(last) else \
                 np.zeros(last.slots.shape, np.int64)
@@ -420,13 +492,31 @@ def main():
             eng.close()
         return elapsed, last, timers, digests, sh, int(idx.size), (rating, cons)
 
-    boundary_us = measure_boundary_us(torch) if rank == 0 else None
+    def secondary_pool_leg(w, n, steps, traffic_path=None):
+        """A whole pool on this GPU beside the main line: value, step, walk, exactness and (1M pools) its roofline."""
+        el, l, tm, dg, _, _, _ = shared_pool_run(w, n, 1, 0, steps, 1, collective=False)
+        key = workload_key(w["mode"], n, w["window"], args.dist)
+        want = expected_digest(key)
+        step_ms = el / steps * 1e3
+        walk_ms = float(np.mean(tm["walk"]))
+        out = {"workload": w["describe"](n), "value": float(l.stats["players_matched"]) * steps / el,
+               "unit": "matched players/s", "ms_per_step": step_ms, "steps": steps,
+               "passes_max": int(l.stats["passes_max"]), "walk_ms": walk_ms, "pairs_per_step": float(l.stats["pairs"]),
+               "exact": (union_digest(dg) == want) if want else None,
+               "exactness": {"emission_digest": union_digest(dg), "oracle_digest": want, "key": key}}
+        if traffic_path:
+            traffic, tnote = load_traffic(traffic_path, n, w["mode"])
+            out["roofline"] = roofline_block(w["mode"], float(l.stats["pairs"]), w["bytes_per_pair"], walk_ms, step_ms, n,
+                                             int(l.stats["passes_max"]), traffic, boundary_us, tnote)
+        return out
+
+    boundary_us = measure_boundary_us(torch) if (rank == 0 and not args.no_boundary) else None
     tdefault = os.path.join(ROOT, "profiles",
                             "traffic_latest.json" if args.mode == "1v1" else "traffic_latest_%s.json" % args.mode)
 
     # ------------------------------------------------------------------ the main leg
     n = args.players if args.players else (1_000_000 if world == 1 else 10_000_000)
-    elapsed, last, timers, digests, sh, n_mine, (rating, cons) = shared_pool_run(n, world, rank, args.steps, args.warmup)
+    elapsed, last, timers, digests, sh, n_mine, (rating, cons) = shared_pool_run(wl, n, world, rank, args.steps, args.warmup)
     st = last.stats if last is not None else {"players_matched": 0, "pairs": 0, "passes_max": 0}
     part = {"rank": rank, "elapsed": elapsed, "players": n_mine, "matched_per_step": int(st["players_matched"]),
             "pairs": int(st["pairs"]), "passes_max": int(st["passes_max"]),
@@ -447,7 +537,7 @@ def main():
         got = {}
         for p in parts:
             got.update(p["digests"])
-        key = workload_key(args.mode, n, window, args.dist)
+        key = workload_key(args.mode, n, wl["window"], args.dist)
         want = expected_digest(key)
         traffic, tnote = (None, "PMC traffic is per single-GPU tick; not collected for the sharded run")
         if world == 1:
@@ -470,8 +560,9 @@ def main():
             "config": {
                 "workload": describe(n) if world == 1 else
                             "%s — ONE pool sharded across %dxMI355X by (game mode, rating group)" % (describe(n), world),
-                "baseline_config": "configs[1]" if (world == 1 and n == 1_000_000) else
-                                   ("configs[3]" if (world > 1 and n == 10_000_000 and args.mode == "1v1") else "custom"),
+                "baseline_config": "configs[1]" if (world == 1 and n == 1_000_000 and args.mode == "1v1") else
+                                   ("configs[2]" if (world == 1 and n == 1_000_000 and args.mode == "5v5") else
+                                    ("configs[3]" if (world > 1 and n == 10_000_000 and args.mode == "1v1") else "custom")),
                 "rating_groups": 7,
                 "sharding": dict(sh.describe(), **{
                     "collective": "none on the data path (chains never interact: reference lib/application.ex:26-40, "
@@ -494,41 +585,76 @@ def main():
             "passes_max": max(p["passes_max"] for p in parts),
             "kernel_ms": {"walk": slow["walk_ms"], "bucket(count+scan+scatter)": slow["bucket_ms"],
                           "d2h+bookkeeping": slow["copy_ms"], "of_rank": slow["rank"]},
-            "roofline": roofline_block(args.mode, pairs, bytes_per_pair, slow["walk_ms"], step_ms, n,
+            "roofline": roofline_block(args.mode, pairs, wl["bytes_per_pair"], slow["walk_ms"], step_ms, n,
                                        max(p["passes_max"] for p in parts), traffic, boundary_us, tnote),
         }
         if world == 1 and not args.no_cpu_baseline:
-            cfg_cpu = make_config(modes, capacity=pow2(n), device=local_rank, timing=False)
+            cfg_cpu = make_config(wl["modes"], capacity=pow2(n), device=local_rank, timing=False)
             line["cpu_baseline"] = cpu_baseline(cfg_cpu, rating, cons, args.mode, budget_s=args.cpu_baseline_seconds)
     del rating, cons
 
     # ------------------------------------------------------------------ secondary legs (never `value`)
     if not args.no_secondary:
         if world == 1:
+            # BASELINE configs[2] (5v5, 1M players, roles + rating) beside the configs[1] headline
+            if args.mode == "1v1" and not args.no_cfg3:
+                w3 = workload("5v5")
+                line["cfg3"] = dict(secondary_pool_leg(w3, n, max(2, args.cfg3_steps),
+                                                       os.path.join(ROOT, "profiles", "traffic_latest_5v5.json")),
+                                    baseline_config="configs[2]" if n == 1_000_000 else "custom")
             # cfg-4's pool on ONE GPU: the N=1 point of the strong-scaling curve of `--gpus N`
             n10 = args.shared_players
             if n10 and n10 != n:
                 steps10 = max(2, min(args.steps, 8))
-                el, l10, tm, dg, _, _, _ = shared_pool_run(n10, 1, 0, steps10, 1)
-                k10 = workload_key(args.mode, n10, window, args.dist)
-                line["shared_pool_n1"] = {
-                    "workload": describe(n10), "value": float(l10.stats["players_matched"]) * steps10 / el,
-                    "unit": "matched players/s", "ms_per_step": el / steps10 * 1e3, "steps": steps10,
-                    "passes_max": int(l10.stats["passes_max"]), "walk_ms": float(np.mean(tm["walk"])),
-                    "exact": (union_digest(dg) == expected_digest(k10)) if expected_digest(k10) else None}
+                sp = secondary_pool_leg(wl, n10, steps10)
+                if not args.no_prediction:
+                    # what `--gpus N` will show: every rank's share of this pool run ALONE on this GPU
+                    pred = {}
+                    for nr in (2, 4, 8):
+                        per_rank = []
+                        for r in range(nr):
+                            el, l, tm, _, shp, held, _ = shared_pool_run(wl, n10, nr, r, 3, 1, collective=False)
+                            per_rank.append({"rank": r, "players": held, "ms_per_step": el / 3 * 1e3,
+                                             "walk_ms": float(np.mean(tm["walk"])) if tm["walk"] else 0.0,
+                                             "passes_max": int(l.stats["passes_max"]) if l is not None else 0,
+                                             "chains": [list(c) for c in shp.chains_of(r)]})
+                        pred[str(nr)] = {"per_rank": per_rank, "load_share_bound": shp.bound(),
+                                         "predicted_speedup": predict_speedup(sp["ms_per_step"],
+                                                                              [p["ms_per_step"] for p in per_rank])}
+                    sp["sharding_prediction"] = dict(pred, note=(
+                        "strong scaling of this pool by (game mode, rating group) chain, measured on ONE GPU: the step of "
+                        "the whole pool over the slowest rank's share run alone.  One GPU already runs all chains "
+                        "concurrently in the same launches, so the heaviest chain's passes bound every N — "
+                        "the load share (load_share_bound) is not the bound (DESIGN.md section 7)"))
+                line["shared_pool_n1"] = sp
             if args.concurrent_pools > 1:
-                ccfg = make_config(modes, capacity=pow2(n), device=local_rank, timing=False)
+                ccfg = make_config(wl["modes"], capacity=pow2(n), device=local_rank, timing=False)
 
                 def pool_inputs(k):
-                    r, c = make_pool(n, seed=101 + k, dist=args.dist, **pool_kw)
+                    r, c = make_pool(n, seed=101 + k, dist=args.dist, **wl["pool_kw"])
                     return torch.from_numpy(r).cuda(), torch.from_numpy(c.view(np.int32)).cuda()
 
                 line["concurrent_pools"] = concurrent_pools(lambda: Engine(ccfg), args.concurrent_pools,
                                                             max(2, min(args.steps, 20)), pool_inputs)
         else:
+            # the N=1 point of this very pool, on rank 0 alone (the others wait at the barrier): the speed-up of
+            # the sharded run is measured inside ONE launch of bench.py, from the gathered per-rank records
+            if not args.no_prediction:
+                n1 = None
+                if rank == 0:
+                    el, _, _, _, _, _, _ = shared_pool_run(wl, n, 1, 0, 3, 1, collective=False)
+                    n1 = el / 3 * 1e3
+                fence()
+                if rank == 0:
+                    per_rank_ms = [p["elapsed"] / args.steps * 1e3 for p in parts]
+                    line["config"]["sharding"]["one_gpu_ms_per_step"] = n1
+                    line["config"]["sharding"]["speedup_vs_one_gpu"] = predict_speedup(n1, per_rank_ms)
+                    line["config"]["sharding"]["speedup_note"] = (
+                        "the whole pool on rank 0's GPU alone (3 steps) over the slowest rank's step of the sharded run; "
+                        "bounded by the heaviest chain's passes, not by load_share_bound (DESIGN.md section 7)")
             # weak scaling: every rank its own 1M pool (what round 1 reported as the value)
-            r1, c1 = make_pool(args.weak_players, seed=1 + rank, dist=args.dist, **pool_kw)
-            wcfg = make_config(modes, capacity=pow2(args.weak_players), device=local_rank, timing=False)
+            r1, c1 = make_pool(args.weak_players, seed=1 + rank, dist=args.dist, **wl["pool_kw"])
+            wcfg = make_config(wl["modes"], capacity=pow2(args.weak_players), device=local_rank, timing=False)
             d_r, d_c = torch.from_numpy(r1).cuda(), torch.from_numpy(c1.view(np.int32)).cuda()
             wsteps = max(2, min(args.steps, 20))
             with Engine(wcfg) as weng:
@@ -552,23 +678,25 @@ def main():
                 line["weak_scaling"] = {"value": float(ss.item()) / float(tt[0].item()), "unit": "matched players/s",
                                         "pool_per_gpu": args.weak_players, "steps": wsteps,
                                         "ms_per_step": float(tt[0].item()) / wsteps * 1e3,
-                                        "note": "every rank its own pool (independent pools of a node); "
-                                                "secondary, never `value`"}
+                                        "note": "every rank its own pool (independent pools of a node: the node-level "
+                                                "throughput lever under the reference's partition); secondary, never `value`"}
+    pools.clear()
 
     if not args.no_stream:
         w25 = mode_1v1(window=args.window, region_filter=True)
         mix_w = np.outer([0.7, 0.3], [0.30, 0.10, 0.10, 0.10, 0.10, 0.10, 0.20])   # expected share of every chain
+        scap = stream_capacity(args.stream_qps, args.stream_seconds)
         if world == 1 and args.mode == "1v1":
-            scfg = make_config([w25], capacity=1 << 20, device=local_rank, timing=False)
+            scfg = make_config([w25], capacity=scap, device=local_rank, timing=False)
             with ShardedSearch(scfg, Engine, 0, 1) as s1:
                 line["latency"] = stream_leg(s1, None, 0, 1, args.stream_qps, args.stream_seconds, args.stream_tick_ms,
-                                             "1v1 +-%d, region filter" % args.window)
+                                             "1v1 +-%d, region filter" % args.window, "1v1")
         if args.mode == "1v1":
             # BASELINE cfg-5: 70 % 1v1 / 30 % 5v5 (roles as cfg-3), chains = (mode, group) over the ranks
-            mcfg = make_config([w25, mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 20, device=local_rank, timing=False)
+            mcfg = make_config([w25, mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=scap, device=local_rank, timing=False)
             with ShardedSearch(mcfg, Engine, rank, world, mix_w) as sm:
                 res = stream_leg(sm, dist, rank, world, args.stream_qps, args.stream_seconds, args.stream_tick_ms,
-                                 "70 %% 1v1 +-%d region filter / 30 %% 5v5 +-50 five roles" % args.window,
+                                 "70 %% 1v1 +-%d region filter / 30 %% 5v5 +-50 five roles" % args.window, "mixed",
                                  mode_weights=(70, 30), role_weights=ROLE_WEIGHTS_5V5)
                 if rank == 0:
                     res["sharding"] = sm.sharding.describe()

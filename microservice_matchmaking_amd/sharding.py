@@ -84,14 +84,16 @@ class ChainSharding:
         return [r for r in range(self.world_size) if r not in used]
 
     def bound(self):
-        """Best possible speed-up over one rank for this pool: total load / heaviest rank."""
+        """Total load / heaviest rank.  NOT the speed-up to expect: one GPU already runs all chains concurrently,
+        so the pool's step on one GPU is close to its heaviest chain's and sharding gains far less
+        (bench.predict_speedup)."""
         top = float(self.load.max())
         return float(self.weights.sum() / top) if top > 0 else 1.0
 
     def describe(self):
         return {"key": "(game mode, rating group)", "world_size": self.world_size,
                 "owner": self.chain_owner.tolist(), "load_share": (self.load / max(self.load.sum(), 1e-12)).tolist(),
-                "idle_ranks": self.idle_ranks(), "speedup_bound": self.bound()}
+                "idle_ranks": self.idle_ranks(), "load_share_bound": self.bound()}
 
 
 class GroupSharding(ChainSharding):

@@ -21,6 +21,7 @@ import time
 
 import numpy as np
 
+from ._abi import MMError
 from .synth import make_pool
 
 
@@ -59,6 +60,7 @@ def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=
     tick_cost = []
     matched = 0
     first = 0
+    full_at_s = None
     t_start = time.perf_counter()
     for (t_open, t_close, n, sd, ts) in schedule:
         rating, cons = stream_batch(n, sd, mode_weights, role_weights)
@@ -67,7 +69,16 @@ def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=
             while time.perf_counter() - t_start < t_close:      # the period has to be over
                 pass
         t0 = time.perf_counter()
-        search.enqueue(rating, cons, first_global_index=first)
+        try:
+            search.enqueue(rating, cons, first_global_index=first)
+        except MMError as ex:
+            if ex.status != -4:                                 # MM_ERR_FULL: fewer than n free slots in the pool
+                raise
+            # The batch is refused as a whole and nothing of it was queued (include/mm_engine.h): for the
+            # service these deliveries stay unacked in the broker (prefetch back-pressure,
+            # lib/search/worker.ex:29) until lobbies free slots.  The stream ends here and says so.
+            full_at_s = t_open
+            break
         first += n
         for md in range(n_modes):
             m = search.tick(md)
@@ -90,7 +101,7 @@ def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=
         "real": [cat(x) for x in real], "floor": [cat(x) for x in floor],
         "matched": matched, "elapsed": elapsed, "tick_cost": np.asarray(tick_cost),
         "depth": depth, "digests": {k: h.hexdigest() for k, h in hashers.items()}, "lobbies": emitted,
-        "arrivals": total,
+        "arrivals": total, "ingested": first, "full_at_s": full_at_s,
     }
 
 

@@ -44,6 +44,14 @@ def test_roofline_block_reproduces_the_committed_line():
     assert lat["us_per_pass"] == pytest.approx(16000.0 / 600) and lat["traffic_note"] == "stale"
 
 
+def test_predict_speedup_is_the_slowest_rank_not_the_load_share():
+    # BASELINE cfg-4 as measured on one GPU in round 2: the pool 66.8 ms, its 3M-player chain alone ~55 ms
+    assert bench.predict_speedup(66.8, [55.0, 20.0, 0.0, 18.0]) == pytest.approx(66.8 / 55.0)
+    assert bench.predict_speedup(10.0, []) is None and bench.predict_speedup(10.0, [0.0]) is None
+    assert bench.stream_capacity(100_000, 3.0) == 1 << 20 and bench.stream_capacity(100_000, 60.0) == 1 << 21
+    assert bench.stream_key("mixed", 100000, 60.0, 10.0) == "stream/mixed/qps100000/s60/tick10/seed77"
+
+
 def test_traffic_file_is_refused_when_the_kernel_sources_changed(tmp_path):
     good = {"workload_players": 1000, "mode": "1v1", "walk_hbm_bytes_per_tick": 5.0, "source_hash": bench.kernel_source_hash()}
     p = tmp_path / "t.json"
@@ -125,12 +133,27 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
     assert ex["ok"] is True and ex["emission_digest"] == ex["oracle_digest"] and ex["key"].startswith(mode + "/12000/")
     sp = d["shared_pool_n1"]                         # cfg-4's pool on one GPU (here: 20000 players)
     assert sp["exact"] is True and sp["value"] > 0 and "20000 players" in sp["workload"]
+    pr = sp["sharding_prediction"]                   # every rank's share of that pool, alone on this GPU
+    for nr in ("2", "4", "8"):
+        ranks = pr[nr]["per_rank"]
+        assert len(ranks) == int(nr) and sum(r["players"] for r in ranks) == 20000
+        assert pr[nr]["predicted_speedup"] == pytest.approx(
+            sp["ms_per_step"] / max(r["ms_per_step"] for r in ranks))
+        assert pr[nr]["load_share_bound"] >= 1.0
+    assert [r["players"] for r in pr["8"]["per_rank"]].count(0) == 1          # 7 chains on 8 ranks
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     cp = d["concurrent_pools"]                      # opt-in leg: two engines, two host threads
     assert cp["pools"] == 2 and "error" not in cp and cp["value"] > 0 and cp["steps"] == 2
     if mode == "1v1":
+        c3 = d["cfg3"]                               # BASELINE configs[2] beside the headline, checked the same way
+        assert c3["exact"] is True and "5v5" in c3["workload"] and c3["value"] > 0 and c3["steps"] >= 2
+        assert c3["roofline"]["algorithmic_bytes_per_launch"] == c3["pairs_per_step"] * 12
+        assert c3["exactness"]["key"].startswith("5v5/12000/")
         for leg in ("latency", "latency_mixed"):
+            assert d[leg]["ok"] is True and d[leg]["emission_digest"] == d[leg]["oracle_digest"]   # vs the committed oracle run
+            assert d[leg]["capacity_exhausted_at_s"] is None and d[leg]["tick_cost_ms_max"] >= d[leg]["tick_cost_ms_p50"]
+            assert d[leg]["tick_cost_ms_by_10s"][0]["from_s"] == 0.0
             assert d[leg]["p99_ms"] >= d[leg]["p50_ms"] >= 0 and d[leg]["enqueue_qps"] == 20000
             assert d[leg]["floor_p99_ms"] >= d[leg]["floor_p50_ms"] >= 0     # the arrival-limited floor beside it
             assert len(d[leg]["emission_digest"]) == 32
@@ -181,8 +204,13 @@ def test_bench_ranks_dry_run_shards_one_pool(world, oracle_cls):
     ex = d["exactness"]
     assert ex["ok"] is True and ex["emission_digest"] == ex["oracle_digest"]
     assert d["weak_scaling"]["pool_per_gpu"] == 6000 and d["weak_scaling"]["value"] > 0
+    # the speed-up is computed from the gathered per-rank records and rank 0's run of the whole pool
+    assert sh["load_share_bound"] >= 1.0 and "speedup_bound" not in sh
+    assert sh["speedup_vs_one_gpu"] == pytest.approx(
+        bench.predict_speedup(sh["one_gpu_ms_per_step"], [p["ms_per_step"] for p in sh["per_rank"]]))
     lm = d["latency_mixed"]                                           # cfg-5: the two-mode stream, chains over the ranks
     assert lm["ranks"] == world and lm["sharding"]["idle_ranks"] == [] and len(lm["per_mode"]) == 2
+    assert lm["ok"] is True and lm["emission_digest"] == lm["oracle_digest"]       # against the committed oracle run
     # the stream's emission on N ranks is the single oracle engine's
     from microservice_matchmaking_amd.config import make_config, mode_1v1, mode_team
     from microservice_matchmaking_amd.sharding import ShardedSearch, union_digest
