@@ -78,7 +78,7 @@ int mm_decode_players(const mm_config* cfg, const mm_codec_cfg* cc, const char* 
  *   strings  escapes resolved, then \" \\ \n \t \r \f \b, other bytes <= 0x1F and 0x7F as \u00XX with
  *            uppercase hex digits, everything else (UTF-8, "/") raw  (Poison.Encoder.BitString)
  *   integers the digits ("-0" is 0); a number with a fraction or an exponent is a float and is
- *            written as :io_lib_format.fwrite_g/1 writes it (2500.5, 100.0, 1.0e3, 0.001, 1.0e-5)
+ *            written as :io_lib_format.fwrite_g/1 writes it (2500.5, 100.0, 1.0e3, 0.001, 1.0e-5; both zeros as 0.0, as OTP < 27 does)
  *
  * Equivalence bar: byte identity with Poison.encode! for objects of up to 32 members per level
  * (beyond that the VM's hash order decides :maps.keys/1, which cannot be restated; such an object is

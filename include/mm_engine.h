@@ -17,7 +17,9 @@
  *     allocate catches at the boundary (MM_ERR_OOM for std::bad_alloc, MM_ERR_INTERNAL otherwise);
  *   - after MM_ERR_HIP / MM_ERR_INTERNAL / MM_ERR_OOM from mm_tick the device work already queued has
  *     finished (the stream is synchronised before the error is returned) but queues and lobbies are
- *     in a mid-tick state: call mm_reset or mm_restore before using the engine again;
+ *     in a mid-tick state: call mm_reset or mm_restore before using the engine again — until then
+ *     mm_enqueue*, mm_cancel, mm_tick and mm_snapshot answer MM_ERR_STATE, so an owner that only
+ *     logged the error cannot go on to publish lobbies from a half-walked pool;
  *   - one owner per engine, no internal locking: calls on one engine never overlap (one
  *     GenServer owns one engine, as one Search.Worker owns one channel:
  *     lib/search/worker.ex:220-237).  The owner need not stay on one OS thread — a dirty NIF
@@ -76,7 +78,9 @@ typedef enum mm_status {
     MM_ERR_HIP = -5,          /* a HIP runtime call failed; mm_last_hip_error() has it  */
     MM_ERR_INTERNAL = -6,     /* device-side invariant violated (reported, never abort) */
     MM_ERR_ABI = -7,          /* cfg->abi_version != MM_ABI_VERSION                     */
-    MM_ERR_RANGE = -8         /* first/count outside the last tick's match list         */
+    MM_ERR_RANGE = -8,        /* first/count outside the last tick's match list         */
+    MM_ERR_STATE = -9         /* an earlier mm_tick failed: only mm_reset / mm_restore /
+                                 mm_engine_destroy are accepted until one succeeded     */
 } mm_status;
 
 /* Inclusive integer rating range — one row of `config :matchmaking, RatingGroups`

@@ -27,7 +27,7 @@ NO_SLOT = 0xFFFFFFFF
 STATUS_NAMES = {
     0: "MM_OK", -1: "MM_ERR_INVALID_ARG", -2: "MM_ERR_NO_DEVICE", -3: "MM_ERR_OOM",
     -4: "MM_ERR_FULL", -5: "MM_ERR_HIP", -6: "MM_ERR_INTERNAL", -7: "MM_ERR_ABI",
-    -8: "MM_ERR_RANGE",
+    -8: "MM_ERR_RANGE", -9: "MM_ERR_STATE",
 }
 
 

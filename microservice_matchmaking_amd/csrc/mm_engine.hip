@@ -953,6 +953,9 @@ struct mm_engine {
     float* h_rscore;
     uint32_t* h_rpass;
     uint32_t r_n, r_L;
+    bool poisoned;             // a tick failed half way: everything but reset / restore / destroy answers MM_ERR_STATE
+    uint32_t fault_tick;       // MM_DEBUG_FAIL_TICK=k: the k-th mm_tick of this engine fails after its walk (test hook)
+    uint32_t ticks_seen;
 };
 
 static double host_now_ms(void)
@@ -1016,6 +1019,7 @@ extern "C" const char* mm_strerror(int status)
     case MM_ERR_INTERNAL: return "device-side invariant violated";
     case MM_ERR_ABI: return "ABI version mismatch";
     case MM_ERR_RANGE: return "match range out of bounds";
+    case MM_ERR_STATE: return "a tick failed: mm_reset or mm_restore first";
     default: return "unknown status";
     }
 }
@@ -1194,7 +1198,11 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         e->in_cap = 0;
         e->wave_hist_rows = 0;
         e->live_upper = 0;
+        e->poisoned = false;
+        e->ticks_seen = 0;
         {
+            const char* ft = getenv("MM_DEBUG_FAIL_TICK");
+            e->fault_tick = ft ? (uint32_t)strtoul(ft, NULL, 0) : 0u;
             const char* fg = getenv("MM_FORCE_GENERIC");
             e->force_generic = fg && fg[0] == '1';
             const char* pd = getenv("MM_PAIR_DEBUG");
@@ -1327,7 +1335,9 @@ extern "C" int mm_reset(mm_engine* e)
         e->cancel_pending = 0;
         e->r_n = 0;
         e->live_upper = 0;
-        return engine_reset_device(e);
+        const int rc = engine_reset_device(e);
+        if (rc == MM_OK) e->poisoned = false;
+        return rc;
     } catch (const std::bad_alloc&) {
         return MM_ERR_OOM;
     } catch (...) {
@@ -1430,6 +1440,7 @@ extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const
 {
     try {
         if (!e || (n && (!rating || !cons))) return MM_ERR_INVALID_ARG;
+        if (e->poisoned) return MM_ERR_STATE;
         ON_ENGINE_DEVICE(e);
         const double t0 = host_now_ms();
         if (st) memset(st, 0, sizeof(*st));
@@ -1480,6 +1491,7 @@ extern "C" int mm_enqueue_device(mm_engine* e, uint32_t n, const int32_t* d_rati
 {
     try {
         if (!e || (n && (!d_rating || !d_cons))) return MM_ERR_INVALID_ARG;
+        if (e->poisoned) return MM_ERR_STATE;
         ON_ENGINE_DEVICE(e);
         const double t0 = host_now_ms();
         if (st) memset(st, 0, sizeof(*st));
@@ -1526,6 +1538,7 @@ extern "C" int mm_cancel(mm_engine* e, uint32_t n, const uint32_t* slot)
 {
     try {
         if (!e || (n && !slot)) return MM_ERR_INVALID_ARG;
+        if (e->poisoned) return MM_ERR_STATE;
         ON_ENGINE_DEVICE(e);
         std::vector<uint32_t> live;
         live.reserve(n);
@@ -1801,6 +1814,7 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
 extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats)
 {
     if (!e || mode >= e->cfg.n_modes) return MM_ERR_INVALID_ARG;
+    if (e->poisoned) return MM_ERR_STATE;
     ON_ENGINE_DEVICE(e);
     int rc;
     try {
@@ -1816,6 +1830,7 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
         // the engine is used again (mm_engine.h)
         (void)hipStreamSynchronize(e->stream);
         e->r_n = 0;
+        e->poisoned = true;
     }
     return rc;
 }
@@ -1935,6 +1950,7 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
         if (c.passes > pmax) pmax = c.passes;
     }
     if (errf) return MM_ERR_INTERNAL;
+    if (e->fault_tick && ++e->ticks_seen == e->fault_tick) return MM_ERR_INTERNAL;   // test hook: a tick that dies after its walk
     if ((size_t)total * M.L > (size_t)cfg.capacity + (size_t)MM_MAX_LOBBY * G) return MM_ERR_INTERNAL;
     e->r_group.resize(total);
     // The match list, group-major emission order.  The slots go first, group by group, each followed by
@@ -2155,6 +2171,7 @@ extern "C" int mm_snapshot(mm_engine* e, void* buf, uint64_t cap, uint64_t* writ
 {
     try {
         if (!e || !buf || !written) return MM_ERR_INVALID_ARG;
+        if (e->poisoned) return MM_ERR_STATE;                 // a mid-tick pool is not a pool worth keeping
         ON_ENGINE_DEVICE(e);
         uint64_t need = 0;
         int rc = mm_snapshot_size(e, &need);                  // also refreshes h_chains

@@ -20,10 +20,21 @@ defmodule Matchmaking.Search.EngineOwner do
       encoded (`Engine.encode_lobby/4`, worker.ex:315-318) and published to
       `@exchange_forward` / `@queue_forward` exactly as `prepare_game_lobby/4` does (:250-261);
       the rows of its players leave both tables;
-    * durability of the waiting players is the pool snapshot (SURVEY.md 8(f) row 4): `terminate/2`
-      and every `@snapshot_ms` write ONE file holding the engine snapshot AND the slot table
-      (slot -> payload, decoded id), `init/1` restores both — a restored slot always has its row,
-      and nothing is redelivered twice because nothing was left unacked;
+    * durability of the waiting players: the reference never loses a waiting player that was not acked
+      (worker.ex:323) — so a delivery is acked only AFTER its payload is in the JOURNAL (an append-only
+      file, `:file.datasync/1` per ingested batch, i.e. once per tick at most).  The pool snapshot
+      (SURVEY.md 8(f) row 4) only bounds the journal: every `@snapshot_ms` the engine blob is taken in the
+      owner (a device-to-host copy) and handed, with a copy of the slot table, to a separate process that
+      serialises and writes it (`term_to_binary` of a 1M-player table would stall the 10 ms tick loop for
+      hundreds of ms); when the file is in place the journal generation before it is deleted.  `init/1`
+      restores snapshot + slot table and then re-ingests the journalled payloads that were neither
+      emitted nor cancelled since (records `{:out, ids}`).  Loss window of acked players after kill -9: none.
+      What a crash CAN do is re-emit a lobby whose `{:out, _}` record had not reached the disk — the
+      reference has the same at-least-once edge between its publish (worker.ex:319) and its ack (:323);
+    * a failed tick (`{:error, _}` from `Engine.tick/2`: the engine is mid-tick and refuses everything but
+      reset / restore — include/mm_engine.h, MM_ERR_STATE) STOPS the owner without a snapshot; the supervisor
+      restarts it (`restart: :transient`, application.ex:8-14) and `init/1` rebuilds the pool from the last
+      snapshot + journal, exactly as after a crash;
     * `ActiveUser.remove_user/1` callers additionally cast `{:cancel, player_id}` (active_user.ex:57-66)
       with the DECODED id (`player["id"]`, the term the lobby worker holds: game-lobby/worker.ex:80, :96).
       The id table maps it to the slot; the row is checked against the slot's current holder before
@@ -56,22 +67,28 @@ defmodule Matchmaking.Search.EngineOwner do
     case Engine.create(config) do
       {:ok, engine} ->
         slots = :ets.new(:mm_slots, [:set, :private])     # {slot, payload, decoded id}
-        ids = :ets.new(:mm_ids, [:set, :private])         # {decoded id, slot}
-        with path when is_binary(path) <- opts[:snapshot_path],
-             {:ok, file} <- File.read(path),
-             {:mm_pool, 1, blob, rows} <- :erlang.binary_to_term(file, [:safe]),
-             :ok <- Engine.restore(engine, blob) do
-          # the pool and its slot table are ONE unit: a slot the engine can emit always has its row
-          for {slot, payload, id} <- rows do
-            :ets.insert(slots, {slot, payload, id})
-            :ets.insert(ids, {id, slot})
+        ids = :ets.new(:mm_ids, [:bag, :private])         # {decoded id, slot}; a bag: the same id may be delivered twice
+        state = %{engine: engine, config: config, modes: modes, pending: [], opts: opts, failed: false,
+                  slots: slots, ids: ids, publish: Keyword.fetch!(opts, :publish), journal: nil, generation: 0}
+        generation =
+          with path when is_binary(path) <- opts[:snapshot_path],
+               {:ok, file} <- File.read(path),
+               {:mm_pool, 2, gen, blob, rows} <- decode_snapshot(file),
+               :ok <- Engine.restore(engine, blob) do
+            # the pool and its slot table are ONE unit: a slot the engine can emit always has its row
+            for {slot, payload, id} <- rows do
+              :ets.insert(slots, {slot, payload, id})
+              :ets.insert(ids, {id, slot})
+            end
+            Logger.info("search engine: pool of #{length(rows)} players restored from #{path}")
+            gen
+          else
+            _ -> 0                                        # no file, unknown format (logged) or a refused blob: start empty
           end
-          Logger.info("search engine: pool of #{length(rows)} players restored from #{path}")
-        end
+        state = replay_journal(%{state | generation: generation})
         Process.send_after(self(), :tick, @tick_ms)
         if opts[:snapshot_path], do: Process.send_after(self(), :snapshot, @snapshot_ms)
-        {:ok, %{engine: engine, config: config, modes: modes, pending: [], opts: opts,
-                slots: slots, ids: ids, publish: Keyword.fetch!(opts, :publish)}}
+        {:ok, state}
       {:error, {code, text}} ->
         {:stop, {:engine, code, List.to_string(text)}}                  # like {:error, :noconn}, worker.ex:225-228
     end
@@ -82,13 +99,15 @@ defmodule Matchmaking.Search.EngineOwner do
     do: {:noreply, %{state | pending: [{payload, meta, channel} | state.pending]}}
 
   def handle_cast({:cancel, player_id}, state) do
-    with [{_, slot}] <- :ets.lookup(state.ids, player_id),
-         [{_, _payload, ^player_id}] <- :ets.lookup(state.slots, slot) do   # still the slot's holder?
+    # ActiveUser.remove_user/1 removes the id, not a delivery: every slot the id still holds goes
+    for {_, slot} <- :ets.lookup(state.ids, player_id),
+        match?([{_, _payload, ^player_id}], :ets.lookup(state.slots, slot)) do   # still the slot's holder?
       :ok = Engine.cancel(state.engine, <<slot::little-32>>)
       # a cancelled player is never emitted (remove_inactive_players, worker.ex:267-280): its rows go now
       :ets.delete(state.slots, slot)
+      :ets.match_delete(state.ids, {player_id, slot})          # this pair only: never another holder's mapping
     end
-    :ets.delete(state.ids, player_id)          # matched, cancelled or unknown: the id maps to nothing from here on
+    journal(state, {:out, [player_id]}, false)
     {:noreply, state}
   end
 
@@ -96,15 +115,35 @@ defmodule Matchmaking.Search.EngineOwner do
   def handle_info(:tick, state) do
     Process.send_after(self(), :tick, @tick_ms)
     state = ingest(state)
-    state.modes
-    |> Enum.with_index()
-    |> Enum.each(fn {{name, teams, team_size}, mode} -> search(state, name, teams, team_size, mode) end)
-    {:noreply, state}
+    result =
+      state.modes
+      |> Enum.with_index()
+      |> Enum.reduce_while(:ok, fn {{name, teams, team_size}, mode}, :ok ->
+        case search(state, name, teams, team_size, mode) do
+          :ok -> {:cont, :ok}
+          error -> {:halt, error}
+        end
+      end)
+    case result do
+      :ok -> {:noreply, state}
+      # include/mm_engine.h: after a failed tick the pool is mid-tick and the engine answers MM_ERR_STATE to
+      # everything but reset / restore.  Stop WITHOUT snapshotting it; the restart restores snapshot + journal.
+      {:error, {code, text}} -> {:stop, {:engine_tick_failed, code, List.to_string(text)}, %{state | failed: true}}
+    end
   end
 
   def handle_info(:snapshot, state) do
     Process.send_after(self(), :snapshot, @snapshot_ms)
-    write_snapshot(state)
+    {:noreply, write_snapshot(state)}
+  end
+
+  # the writer process reports back: the snapshot of `generation` is in place, older journals can go
+  def handle_info({:snapshot_written, generation}, state) do
+    with path when is_binary(path) <- state.opts[:snapshot_path] do
+      for old <- Path.wildcard(path <> ".journal.*"),
+          String.to_integer(Path.extname(old) |> String.trim_leading(".")) < generation,
+          do: File.rm(old)
+    end
     {:noreply, state}
   end
 
@@ -124,19 +163,22 @@ defmodule Matchmaking.Search.EngineOwner do
     {:ok, slots, _accepted, _rejected} =
       Engine.enqueue(state.engine, pick.(ratings, 4), pick.(cons, 4), pick.(groups, 1))
     kept = for {item, true} <- Enum.zip(Enum.zip([batch, chunk(id_off, 4), chunk(id_len, 4)]), keep), do: item
-    Enum.zip(kept, chunk(slots, 4))
-    |> Enum.each(fn {{{payload, meta, channel}, <<o::little-32>>, <<l::little-32>>}, <<slot::little-32>>} ->
-      if slot != 0xFFFFFFFF do
+    rows =
+      for {{{payload, _meta, _channel}, <<o::little-32>>, <<l::little-32>>}, <<slot::little-32>>} <- Enum.zip(kept, chunk(slots, 4)),
+          slot != 0xFFFFFFFF do
         id = decoded_id(payload, o, l)
         :ets.insert(state.slots, {slot, payload, id})
         :ets.insert(state.ids, {id, slot})
+        payload
       end
-      # the engine holds the player now (or refused it for good: unknown mode / role): ack, as the
-      # reference acks every delivery once its attempt is over (worker.ex:323)
-      AMQP.Basic.ack(channel, meta.delivery_tag)
-    end)
+    # journal first (one datasync per batch), ack after: an acked player is on disk, as an unacked one is in the broker
+    journal(state, {:in, rows}, true)
+    # the engine holds the player now (or refused it for good: unknown mode / role): ack, as the
+    # reference acks every delivery once its attempt is over (worker.ex:323)
+    for {{_payload, meta, channel}, _o, _l} <- kept, channel != :replay, do: AMQP.Basic.ack(channel, meta.delivery_tag)
     # messages the reference would have crashed on (Poison.decode!, worker.ex:292) are rejected, not requeued
-    for {{_payload, meta, channel}, false} <- Enum.zip(batch, keep), do: AMQP.Basic.reject(channel, meta.delivery_tag, requeue: false)
+    for {{_payload, meta, channel}, false} <- Enum.zip(batch, keep), channel != :replay,
+      do: AMQP.Basic.reject(channel, meta.delivery_tag, requeue: false)
     %{state | pending: []}
   end
 
@@ -155,32 +197,116 @@ defmodule Matchmaking.Search.EngineOwner do
     case Engine.tick(state.engine, mode) do
       {:ok, 0, _l, _slots, _scores, _groups, _stats} -> :ok
       {:ok, _n, lobby_size, slots, _scores, _groups, _stats} ->
-        for lobby <- chunk(slots, 4 * lobby_size) do
-          members = for <<slot::little-32 <- lobby>>, do: hd(:ets.lookup(state.slots, slot))
-          {:ok, json} = Engine.encode_lobby(name, teams, team_size, Enum.map(members, &elem(&1, 1)))
-          state.publish.(@exchange_forward, @queue_forward, json)
-          for {slot, _payload, id} <- members do
-            :ets.delete(state.slots, slot)       # the slot goes back to the ring: forget who held it,
-            :ets.delete(state.ids, id)           # and a late {:cancel, id} finds nothing
+        out =
+          for lobby <- chunk(slots, 4 * lobby_size) do
+            members = for <<slot::little-32 <- lobby>>, do: hd(:ets.lookup(state.slots, slot))
+            {:ok, json} = Engine.encode_lobby(name, teams, team_size, Enum.map(members, &elem(&1, 1)))
+            state.publish.(@exchange_forward, @queue_forward, json)
+            for {slot, _payload, id} <- members do
+              :ets.delete(state.slots, slot)               # the slot goes back to the ring: forget who held it,
+              :ets.match_delete(state.ids, {id, slot})     # and only THIS holder's mapping (the id may hold another slot)
+              id
+            end
           end
-        end
-      {:error, {code, text}} -> Logger.error("search engine tick failed: #{code} #{text}")
+        journal(state, {:out, List.flatten(out)}, false)
+        :ok
+      {:error, {code, text}} = error ->
+        Logger.error("search engine tick failed: #{code} #{text}")
+        error
     end
   end
 
   @impl true
+  def terminate(_reason, %{failed: true} = state), do: Engine.close(state.engine)   # never snapshot a mid-tick pool
   def terminate(_reason, state) do
-    write_snapshot(state)
+    write_snapshot(state, :sync)
     Engine.close(state.engine)
   end
 
-  # engine snapshot + slot table in ONE file, written to a temporary name and renamed
-  defp write_snapshot(state) do
+  # ---- durability: journal (what was acked since the last snapshot) + snapshot (what bounds the journal) ----
+
+  # a snapshot file: term_to_binary({:mm_pool, 2, generation, engine_blob, slot_rows}).  Anything else — the raw
+  # engine blob a previous version of this module wrote, a truncated file — is logged and ignored, never raised on.
+  defp decode_snapshot(<<131, _::binary>> = file) do
+    try do
+      :erlang.binary_to_term(file, [:safe])
+    rescue
+      ArgumentError -> Logger.warn("search engine: snapshot file is not a term; starting empty"); :unknown
+    end
+  end
+  defp decode_snapshot(_other), do: (Logger.warn("search engine: snapshot file of an unknown format; starting empty"); :unknown)
+
+  defp journal_path(state, generation), do: state.opts[:snapshot_path] <> ".journal." <> Integer.to_string(generation)
+
+  defp journal(%{journal: nil}, _record, _sync), do: :ok
+  defp journal(_state, {:in, []}, _sync), do: :ok
+  defp journal(_state, {:out, []}, _sync), do: :ok
+  defp journal(state, record, sync) do
+    bin = :erlang.term_to_binary(record)
+    :ok = :file.write(state.journal, [<<byte_size(bin)::32>>, bin])
+    if sync, do: :ok = :file.datasync(state.journal)
+    :ok
+  end
+
+  # after a restart: what the journal of the restored generation says came in and did not go out is ingested again
+  # (fresh slots; the deliveries were acked before the crash, so there is nothing to ack)
+  defp replay_journal(%{opts: opts} = state) do
+    case opts[:snapshot_path] do
+      nil -> state
+      _path ->
+        # every generation from the restored snapshot's on: a crash between "blob taken" and "file in place" leaves
+        # the snapshot of generation g on disk with the journals g (up to the blob) and g + 1 (after it)
+        generations =
+          for file <- Path.wildcard(opts[:snapshot_path] <> ".journal.*"),
+              gen = String.to_integer(Path.extname(file) |> String.trim_leading(".")), gen >= state.generation, do: gen
+        last = Enum.max([state.generation | generations])
+        records = Enum.flat_map(Enum.sort(generations), &read_journal(journal_path(state, &1)))
+        gone = for {:out, ids} <- records, id <- ids, into: MapSet.new(), do: id
+        payloads = for {:in, rows} <- records, payload <- rows, do: payload
+        state = %{state | generation: last}
+        {:ok, fd} = :file.open(journal_path(state, last), [:append, :raw, :binary])
+        state = %{state | journal: fd}
+        pending = for payload <- payloads, do: {payload, :replayed, nil}
+        ingest_replayed(%{state | pending: Enum.reverse(pending)}, gone)
+    end
+  end
+
+  defp read_journal(path) do
+    case File.read(path) do
+      {:ok, bin} -> for <<n::32, rec::binary-size(n) <- bin>>, do: :erlang.binary_to_term(rec, [:safe])   # a torn tail is dropped
+      _ -> []
+    end
+  end
+
+  # ingest/1 without acks and without journalling again; players whose id left after they came in are skipped
+  defp ingest_replayed(%{pending: []} = state, _gone), do: state
+  defp ingest_replayed(state, gone) do
+    keep = for {payload, _, _} <- Enum.reverse(state.pending),
+               id = Poison.decode!(payload)["id"], not MapSet.member?(gone, id), do: {payload, %{delivery_tag: nil}, :replay}
+    ingest(%{state | pending: Enum.reverse(keep), journal: nil}) |> Map.put(:journal, state.journal)
+  end
+
+  # engine snapshot + slot table in ONE file, written to a temporary name and renamed — by a process of its own:
+  # only the blob (a device-to-host copy) and the table copy happen in the owner
+  defp write_snapshot(state, how \\ :async) do
     with path when is_binary(path) <- state.opts[:snapshot_path],
          {:ok, blob} <- Engine.snapshot(state.engine) do
-      file = :erlang.term_to_binary({:mm_pool, 1, blob, :ets.tab2list(state.slots)})
-      :ok = File.write(path <> ".tmp", file)
-      File.rename(path <> ".tmp", path)
+      generation = state.generation + 1
+      rows = :ets.tab2list(state.slots)
+      owner = self()
+      write = fn ->
+        file = :erlang.term_to_binary({:mm_pool, 2, generation, blob, rows})
+        :ok = File.write(path <> ".tmp", file, [:sync])
+        :ok = File.rename(path <> ".tmp", path)
+        send(owner, {:snapshot_written, generation})
+      end
+      # from here on the journal of the NEW generation takes the acks; the old one stays until the file is in place
+      if state.journal, do: :file.close(state.journal)
+      {:ok, fd} = :file.open(journal_path(state, generation), [:append, :raw, :binary])
+      if how == :sync, do: write.(), else: spawn(write)
+      %{state | generation: generation, journal: fd}
+    else
+      _ -> state
     end
   end
 

@@ -172,3 +172,12 @@ def test_team_short_chains_stay_with_k_walk(oracle_cls):
         assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
         assert_same_tick(a.tick(0), b.tick(0), "mixed")
         assert_same_state(a, b, cfg)
+
+
+def test_team_path_on_a_starving_stream(oracle_cls):
+    """The regime cfg-5's 60 s run ends in (helpers.run_starving_team_stream; the GPU twin is in test_gpu_parity.py):
+    long chains, a handful of lobbies per tick, cancels every other tick — on the small geometry (TT_MIN = 64)."""
+    from helpers import run_starving_team_stream
+    per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=9000, ticks=14, per_tick=60, cancels=6,
+                                          capacity=1 << 14)
+    assert depth.min() >= 64 and sum(per) > 0

@@ -139,6 +139,15 @@ def test_gpu_streaming_ticks_mixed_modes(gpu_cls, oracle_cls):
             assert_same_state(a, b, cfg, "tick %d" % tick)
 
 
+def test_gpu_team_path_on_a_starving_stream(gpu_cls, oracle_cls):
+    """What the 60 s run of cfg-5 turns into (profiles/r03_bench_stream60*.json: 5v5 backlog 905k players): every 5v5
+    chain on the team path (>= 4096 players), a handful of lobbies per tick, cancels trickling in."""
+    from helpers import run_starving_team_stream
+    per, depth = run_starving_team_stream(gpu_cls, oracle_cls)
+    assert depth.min() >= 4096, depth                          # all seven chains take the team path
+    assert 0 < np.median(per) <= 40 and min(per[5:]) <= 5 * 7, per      # a handful of lobbies per chain and tick
+
+
 def test_gpu_device_resident_enqueue(gpu_cls, oracle_cls):
     """mm_enqueue_device: inputs already in HBM (the benchmark path) == host-pointer path."""
     import torch

@@ -170,6 +170,38 @@ def test_errors_are_tuples_and_bad_arguments_raise(beam):
     beam.gc()
 
 
+def test_a_failed_tick_is_refused_until_restore(beam, monkeypatch):
+    """include/mm_engine.h: after a tick that failed half way the pool is in a mid-tick state.  The engine says so
+    itself — enqueue / cancel / tick / snapshot answer MM_ERR_STATE (-9) until reset/1 or restore/2 succeeded — so an
+    owner that only logged the error (native/elixir/search_engine_owner.ex stops instead) cannot publish lobbies from
+    a half-walked pool.  MM_DEBUG_FAIL_TICK is the engine's test hook: its k-th tick dies after the walk."""
+    cfg = make_config(MODES, capacity=1 << 12)
+    rating, cons = make_pool(3000, seed=33)
+    cols = (rating.astype("<i4").tobytes(), cons.astype("<u4").tobytes(), b"")
+    ok, good = beam.call("create", cfg_bin(cfg))
+    beam.call("enqueue", good, *cols)
+    ok, blob = beam.call("snapshot", good)                     # the last good snapshot of the owner
+    monkeypatch.setenv("MM_DEBUG_FAIL_TICK", "1")
+    ok, eng = beam.call("create", cfg_bin(cfg))
+    monkeypatch.delenv("MM_DEBUG_FAIL_TICK")
+    assert beam.call("enqueue", eng, *cols)[0] == "ok"
+    tag, (code, text) = beam.call("tick", eng, 0)
+    assert tag == "error" and code == -6 and text
+    for call in (("tick", eng, 0), ("enqueue", eng, *cols), ("cancel", eng, np.zeros(1, "<u4").tobytes()),
+                 ("snapshot", eng)):
+        tag, (code, text) = beam.call(*call)
+        assert tag == "error" and code == -9 and "mm_restore" in text, call
+    assert beam.call("restore", eng, blob) == "ok"
+    assert beam.call("tick", eng, 0) == beam.call("tick", good, 0)          # the pool of the snapshot, walked once
+    # reset/1 is the other way out (an owner that re-ingests its slot table)
+    monkeypatch.setenv("MM_DEBUG_FAIL_TICK", "1")
+    ok, eng2 = beam.call("create", cfg_bin(cfg))
+    monkeypatch.delenv("MM_DEBUG_FAIL_TICK")
+    assert beam.call("tick", eng2, 0)[0] == "error" and beam.call("tick", eng2, 0)[1][0] == -9
+    assert beam.call("reset", eng2) == "ok" and beam.call("tick", eng2, 0)[0] == "ok"
+    beam.gc()
+
+
 def test_snapshot_restore_through_the_nif(beam):
     cfg = make_config(MODES, capacity=1 << 12)
     ok, a = beam.call("create", cfg_bin(cfg))
