@@ -941,6 +941,7 @@ struct mm_engine {
     uint32_t tk_chunk_stride;
     uint32_t team_batch;       // MM_TEAM_BATCH: passes launched per host look at the chains
     uint32_t team_cap;         // MM_TEAM_CAP: TeamParams.scan_cap
+    uint32_t team_late;        // MM_TEAM_LATE: lobbies per pass at or under which kt_late takes the chains over (0 = never)
     uint32_t dbg_last_w, dbg_last_c;   // MM_PAIR_DEBUG + MM_TEAM_BATCH=1: per-pass deltas of the F counters
     // host
     ChainDev* h_chains;        // pinned, n_chains
@@ -1227,6 +1228,11 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* trb = getenv("MM_TEAM_REBUILD");
             e->team_rebuild = trb ? (uint32_t)strtoul(trb, NULL, 0) : 8u;   // 4 / 6 / 8 measured within 0.1 ms of each other, 16: +0.9 ms, every pass: +1.4 ms
             if (e->team_rebuild < 1u) e->team_rebuild = 1u;
+            const char* tlt = getenv("MM_TEAM_LATE");
+            // measured on cfg-3 (profiles/r03_ab_team_late.txt): 0: 12.99 ms, 3: 12.50, 6: 12.46, 12: 12.76, 20: 13.67, 40: 15.73 per tick —
+            // a look-up costs the chaser ~5 us (dependent trips to memory at ~1.5 us each when seven workgroups are all
+            // that runs), so it only beats the three launches of a pass while a pass seats a handful of lobbies
+            e->team_late = tlt ? (uint32_t)strtoul(tlt, NULL, 0) : 6u;
             const char* tcap = getenv("MM_TEAM_CAP");
             e->team_cap = tcap ? (uint32_t)strtoul(tcap, NULL, 0) : TT_SCAN_CAP;
             if (e->team_cap < 1u) e->team_cap = 1u;
@@ -1312,8 +1318,19 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         }
         CREATE_CHK(hipHostMalloc((void**)&e->h_chains, e->n_chains * sizeof(ChainDev), hipHostMallocDefault));
         CREATE_CHK(hipHostMalloc((void**)&e->h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault));
-    #undef CREATE_CHK
         e->h_state.assign(cap, MM_ST_FREE);
+        if (e->tk_memb) {
+            // the first launch of a kernel is slow (8 ms for kt_late in a stream's first late tick): take it here, on
+            // chain records that say "not walked" (the workgroups return at once)
+            TeamParams W;
+            memset(&W, 0, sizeof(W));
+            W.n_groups = cfg->n_groups;
+            W.tchains = e->d_tchains;
+            W.chains = e->d_chains;
+            hipLaunchKernelGGL(kt_late, dim3(cfg->n_groups), dim3(TL_THREADS), 0, e->stream, W);
+            CREATE_CHK(hipGetLastError());
+        }
+    #undef CREATE_CHK
         rc = engine_reset_device(e);
         if (rc) { mm_engine_destroy(e); return rc; }
         *out = e;
@@ -1754,15 +1771,18 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     if (ex > 256u) ex = 256u;
     hipLaunchKernelGGL(kt_pack, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
+    // Batches of passes between two looks at the chains.  The first is short (a tick of a stream seats a handful of
+    // lobbies and is over after two passes); once every chain that is still walked emits at most `team_late` lobbies
+    // per pass, kt_late walks them to their end in one launch (mm_team.inc).
+    uint32_t pass = 0, batch = e->team_batch < 2u ? e->team_batch : 2u;
     for (uint32_t guard = 0;; ++guard) {
         // a pass that changes nothing ends a chain and every other pass seats somebody
-        if (guard > cfg.capacity / e->team_batch + 64u) return MM_ERR_INTERNAL;
-        for (uint32_t b = 0; b < e->team_batch; ++b) {
+        if (guard > cfg.capacity + 64u) return MM_ERR_INTERNAL;
+        for (uint32_t b = 0; b < batch; ++b, ++pass) {
             // the first passes of a tick emit hundreds of lobbies each: the chase takes them two at a time (kt_f2)
-            P.use_f2 = guard * e->team_batch + b < e->team_f2 ? 1u : 0u;
+            P.use_f2 = pass < e->team_f2 ? 1u : 0u;
             // the role sub-queues are rebuilt in the first two passes (a head that sat out the first one is back in
             // the second) and every team_rebuild passes after; in between, players that leave are tombstones in them
-            const uint32_t pass = guard * e->team_batch + b;
             if (pass < 2u || pass % e->team_rebuild == 0u)
                 hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
             hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
@@ -1774,9 +1794,15 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipMemcpyAsync(e->h_tchains, e->d_tchains, G * sizeof(TeamChain), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
-        bool busy = false;
-        for (uint32_t g = 0; g < G; ++g)
-            if (e->h_tchains[g].fast && !e->h_tchains[g].done) busy = true;
+        bool busy = false, late = e->team_late != 0u;
+        uint32_t most = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            const TeamChain& t = e->h_tchains[g];
+            if (!t.fast || t.done) continue;
+            busy = true;
+            most = t.n_vis > most ? t.n_vis : most;
+            if (t.n_vis > e->team_late || t.m > TL_BITS_MAX) late = false;
+        }
         if (e->pair_debug && e->team_batch == 1u) {   // MM_TEAM_BATCH=1: one line per pass, the longest chain
             uint32_t gl = 0;
             for (uint32_t g = 1; g < G; ++g)
@@ -1789,6 +1815,29 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             e->dbg_last_c = tc.dbg[4];
         }
         if (!busy) break;
+        if (late) {
+            hipLaunchKernelGGL(kt_late, dim3(G), dim3(TL_THREADS), 0, e->stream, P);
+            HIPCHK(e, hipGetLastError());
+            if (e->pair_debug) {
+                uint32_t p0[MM_MAX_GROUPS];
+                for (uint32_t g = 0; g < G; ++g) p0[g] = e->h_tchains[g].passes;
+                HIPCHK(e, hipMemcpyAsync(e->h_tchains, e->d_tchains, G * sizeof(TeamChain), hipMemcpyDeviceToHost, e->stream));
+                HIPCHK(e, hipStreamSynchronize(e->stream));
+                for (uint32_t g = 0; g < G; ++g)
+                    if (e->h_tchains[g].fast && e->h_tchains[g].passes != p0[g])
+                    {
+                        const TeamChain& t = e->h_tchains[g];
+                        fprintf(stderr, "[mm-team-late] g%u: kt_late walked passes %u..%u (%u lobbies at the switch; m %u, sub-queues %u %u %u %u %u): "
+                                "%u lobbies by record, %u looked up, %u left open, %u stored fills; entries scanned per role %u %u %u %u %u; "
+                                "cycles/16: records %u look-ups %u fills %u ring waits %u all %u\n", g, p0[g], t.passes, most, t.m,
+                                t.len[0], t.len[1], t.len[2], t.len[3], t.len[4], t.lt[1], t.lt[2], t.lt[3], t.lt[4],
+                                t.lt[5], t.lt[6], t.lt[7], t.lt[8], t.lt[9], t.lt[10], t.lt[11], t.lt[12], t.lt[14], t.lt[13]);
+                    }
+            }
+            break;
+        }
+        // close to the switch: look again soon (a look costs a D2H round trip, an idle pass three launches)
+        batch = (e->team_late && most <= 3u * e->team_late) ? (e->team_batch < 4u ? e->team_batch : 4u) : e->team_batch;
     }
     hipLaunchKernelGGL(kt_fin_scatter, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
     hipLaunchKernelGGL(kt_fin_copy, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);

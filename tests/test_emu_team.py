@@ -181,3 +181,21 @@ def test_team_path_on_a_starving_stream(oracle_cls):
     per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=9000, ticks=14, per_tick=60, cancels=6,
                                           capacity=1 << 14)
     assert depth.min() >= 64 and sum(per) > 0
+
+
+@pytest.mark.parametrize("late", ["0", "1000"])
+def test_kt_late_takes_the_chains_over_at_any_point(oracle_cls, monkeypatch, late):
+    """kt_late (one persistent workgroup per chain for the passes that seat a handful of lobbies) must give the pass
+    kernels' results wherever the hand-over happens: MM_TEAM_LATE=1000 hands every chain over after the first batch
+    (two passes), 0 never does.  Cancel ticks, stored lobbies and the starving stream included."""
+    from helpers import run_starving_team_stream
+    monkeypatch.setenv("MM_TEAM_LATE", late)
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=3, weights=W5) > 50
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=4, regions=2) > 50
+    per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=8, per_tick=80, cancels=9,
+                                          capacity=1 << 14)
+    assert sum(per) > 0
+    cfg = make_config([mode_team(3, 2, 400, (2, 1), region_filter=True)], capacity=1 << 13)
+    rng = np.random.default_rng(5)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        random_scenario(rng, cfg, a, b, n_rounds=4, batch=1500, cancel_frac=0.05)
