@@ -949,11 +949,22 @@ struct mm_engine {
     std::vector<uint8_t> h_state;
     uint32_t next_slot;
     uint32_t cancel_pending;
-    std::vector<uint32_t> r_group, r_released;
+    std::vector<uint32_t> r_released;
     uint32_t* h_rslots;        // pinned: the last tick's lobbies (slots, score, pass), emission order
     float* h_rscore;
     uint32_t* h_rpass;
     uint32_t r_n, r_L;
+    // The match list travels while the walk is still running: at every look the host takes at the chains, the
+    // lobbies emitted since the last look go out on a stream of their own (emission lists only grow).  Group g's
+    // lobbies live at h_r*[r_base[g] ..) — r_base from the most a group can emit (its players at the start of the
+    // tick), so a lobby's place is known before the tick is over; r_cnt / r_pre index them for mm_matches.
+    hipStream_t copy_stream;
+    hipEvent_t ev_copy;
+    bool ev_copy_pending;
+    uint32_t r_base[MM_MAX_GROUPS], r_cnt[MM_MAX_GROUPS], r_pre[MM_MAX_GROUPS + 1];
+    uint32_t r_sent[MM_MAX_GROUPS];     // lobbies of the running tick already on their way / arrived
+    uint32_t r_marked[MM_MAX_GROUPS];   // ... whose players' slots are FREE in h_state already
+    bool r_based;
     bool poisoned;             // a tick failed half way: everything but reset / restore / destroy answers MM_ERR_STATE
     uint32_t fault_tick;       // MM_DEBUG_FAIL_TICK=k: the k-th mm_tick of this engine fails after its walk (test hook)
     uint32_t ticks_seen;
@@ -1162,6 +1173,8 @@ extern "C" void mm_engine_destroy(mm_engine* e)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (uint32_t i = 0; i < MM_MAX_GROUPS; ++i)
         if (e->ev_grp[i]) (void)hipEventDestroy(e->ev_grp[i]);
+    if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1256,6 +1269,12 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         for (int i = 0; i < 4; ++i) CREATE_CHK(hipEventCreate(&e->ev[i]));
         for (uint32_t i = 0; i < cfg->n_groups; ++i) CREATE_CHK(hipEventCreate(&e->ev_grp[i]));
+        CREATE_CHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        CREATE_CHK(hipEventCreate(&e->ev_copy));
+        e->ev_copy_pending = false;
+        e->r_based = false;
+        memset(e->r_cnt, 0, sizeof(e->r_cnt));
+        memset(e->r_pre, 0, sizeof(e->r_pre));
         CREATE_CHK(hipMalloc((void**)&e->d_q_rating, e->n_chains * cap * sizeof(int32_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_q_cons, e->n_chains * cap * sizeof(uint32_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_q_slot, e->n_chains * cap * sizeof(uint32_t)));
@@ -1293,9 +1312,10 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
             CREATE_CHK(hipHostMalloc((void**)&e->h_pchains, cfg->n_groups * sizeof(PairChain), hipHostMallocDefault));
             // a tick emits at most (cap + lobby) / 2 lobbies per group, cap + lobbies-in-progress players overall
-            CREATE_CHK(hipHostMalloc((void**)&e->h_rslots, (cap + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
-            CREATE_CHK(hipHostMalloc((void**)&e->h_rscore, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(float), hipHostMallocDefault));
-            CREATE_CHK(hipHostMalloc((void**)&e->h_rpass, (cap / 2 + (size_t)MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
+            // (+ one lobby of slack per group: a group's region is sized by the players it holds when the tick begins)
+            CREATE_CHK(hipHostMalloc((void**)&e->h_rslots, (cap + (size_t)3 * MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
+            CREATE_CHK(hipHostMalloc((void**)&e->h_rscore, (cap / 2 + (size_t)3 * MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(float), hipHostMallocDefault));
+            CREATE_CHK(hipHostMalloc((void**)&e->h_rpass, (cap / 2 + (size_t)3 * MM_MAX_LOBBY * cfg->n_groups + 64) * sizeof(uint32_t), hipHostMallocDefault));
             CREATE_CHK(hipMemsetAsync(e->d_pchains, 0, cfg->n_groups * sizeof(PairChain), e->stream));
             e->tk_chunk_stride = (uint32_t)(e->pk_stride / TT_CH + 2);
             CREATE_CHK(hipMalloc((void**)&e->d_tchains, cfg->n_groups * sizeof(TeamChain)));
@@ -1583,6 +1603,72 @@ extern "C" int mm_cancel(mm_engine* e, uint32_t n, const uint32_t* slot)
     }
 }
 
+// ---- the match list on its way to the host while the walk runs --------------------------------------------------
+#ifndef MM_RESULTS_MIN_PAIR
+#define MM_RESULTS_MIN_PAIR 16384u   // new lobbies at a look at the chains that are worth a batch of copies (the logic tests build with less)
+#endif
+#ifndef MM_RESULTS_MIN_TEAM
+#define MM_RESULTS_MIN_TEAM 4096u
+#endif
+// r_base: where group g's lobbies live in h_r*.  `before[g]`: the players the group holds as the tick begins (queue +
+// stored lobby + cancelled entries): it cannot emit more than before / L lobbies.
+static void results_set_bases(mm_engine* e, const uint32_t* before, uint32_t L)
+{
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < e->cfg.n_groups; ++g) {
+        e->r_base[g] = run;
+        run += before[g] / L + 1u;
+    }
+    e->r_based = true;
+}
+
+// the players of lobbies [from, to) of group g are matched: their slots are FREE again (ActiveUser.remove_user for
+// the matched players, game-lobby/worker.ex:73-103)
+static void results_mark(mm_engine* e, uint32_t g, uint32_t to, uint32_t L)
+{
+    const uint32_t from = e->r_marked[g];
+    if (to <= from) return;
+    const uint32_t* const sl = e->h_rslots + (size_t)(e->r_base[g] + from) * L;
+    for (size_t i = 0, n = (size_t)(to - from) * L; i < n; ++i) e->h_state[sl[i]] = MM_ST_FREE;
+    e->r_marked[g] = to;
+}
+
+// what arrived with the last batch of copies: release the slots (host work while the device walks on)
+static int results_absorb(mm_engine* e, uint32_t L)
+{
+    if (!e->ev_copy_pending) return MM_OK;
+    HIPCHK(e, hipEventSynchronize(e->ev_copy));
+    e->ev_copy_pending = false;
+    for (uint32_t g = 0; g < e->cfg.n_groups; ++g) results_mark(e, g, e->r_sent[g], L);
+    return MM_OK;
+}
+
+// lobbies [r_sent[g], n_out[g]) of every group go out on the copy stream.  The emission lists only grow and every
+// kernel that wrote entries below n_out has finished (the caller has just synchronised the engine stream).
+static int results_send(mm_engine* e, const uint32_t* n_out, uint32_t L, uint32_t min_new)
+{
+    uint32_t fresh = 0;
+    for (uint32_t g = 0; g < e->cfg.n_groups; ++g) fresh += n_out[g] > e->r_sent[g] ? n_out[g] - e->r_sent[g] : 0u;
+    if (fresh < min_new) return MM_OK;
+    int rc = results_absorb(e, L);                       // one batch of copies in flight at a time
+    if (rc) return rc;
+    for (uint32_t g = 0; g < e->cfg.n_groups; ++g) {
+        const uint32_t a = e->r_sent[g], b = n_out[g];
+        if (b <= a) continue;
+        const size_t at = (size_t)e->r_base[g] + a;
+        HIPCHK(e, hipMemcpyAsync(&e->h_rslots[at * L], e->d_out_slots + (size_t)g * e->out_slot_stride + (size_t)a * L,
+                                 (size_t)(b - a) * L * sizeof(uint32_t), hipMemcpyDeviceToHost, e->copy_stream));
+        HIPCHK(e, hipMemcpyAsync(&e->h_rscore[at], e->d_out_score + (size_t)g * e->out_rec_stride + a, (size_t)(b - a) * sizeof(float),
+                                 hipMemcpyDeviceToHost, e->copy_stream));
+        HIPCHK(e, hipMemcpyAsync(&e->h_rpass[at], e->d_out_pass + (size_t)g * e->out_rec_stride + a, (size_t)(b - a) * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, e->copy_stream));
+        e->r_sent[g] = b;
+    }
+    HIPCHK(e, hipEventRecord(e->ev_copy, e->copy_stream));
+    e->ev_copy_pending = true;
+    return MM_OK;
+}
+
 // The pair path (mm_pair.inc) for every chain of `mode` it is eligible for; the others are
 // left to k_walk (PairChain.fast == 0).  All launches are asynchronous on the engine stream.
 static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
@@ -1653,6 +1739,14 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 tiled = true;
                 compact |= pc.want_compact != 0;
                 longest = pc.m > longest ? pc.m : longest;
+            }
+            // the lobbies emitted so far leave for the host while the next batch runs (the first look sizes the groups' regions)
+            {
+                uint32_t bf[MM_MAX_GROUPS], no[MM_MAX_GROUPS];
+                for (uint32_t g = 0; g < G; ++g) { bf[g] = e->h_pchains[g].before; no[g] = e->h_pchains[g].fast ? e->h_pchains[g].n_out : 0u; }
+                if (!e->r_based) results_set_bases(e, bf, M.L);
+                int src = results_send(e, no, M.L, MM_RESULTS_MIN_PAIR);
+                if (src) return src;
             }
             if (!tiled) break;
             // tile length of this batch: the smallest that keeps the longest chain within PK_TILES_MAX tiles (the
@@ -1814,6 +1908,13 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             e->dbg_last_w = tc.dbg[5];
             e->dbg_last_c = tc.dbg[4];
         }
+        {   // the lobbies emitted so far leave for the host while the next passes run
+            uint32_t bf[MM_MAX_GROUPS], no[MM_MAX_GROUPS];
+            for (uint32_t g = 0; g < G; ++g) { bf[g] = e->h_tchains[g].before; no[g] = e->h_tchains[g].fast ? e->h_tchains[g].n_out : 0u; }
+            if (!e->r_based) results_set_bases(e, bf, M.L);
+            int src = results_send(e, no, M.L, MM_RESULTS_MIN_TEAM);
+            if (src) return src;
+        }
         if (!busy) break;
         if (late) {
             hipLaunchKernelGGL(kt_late, dim3(G), dim3(TL_THREADS), 0, e->stream, P);
@@ -1894,6 +1995,9 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     const bool purge = e->cancel_pending > 0;
     e->r_n = 0;
     e->r_L = M.L;
+    if (e->ev_copy_pending) { (void)hipEventSynchronize(e->ev_copy); e->ev_copy_pending = false; }   // (a tick that failed half way)
+    e->r_based = false;
+    for (uint32_t g = 0; g < G; ++g) { e->r_sent[g] = 0; e->r_marked[g] = 0; e->r_cnt[g] = 0; }
 
     HIPCHK(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t), e->stream));
     if (timing) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
@@ -2001,41 +2105,34 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     if (errf) return MM_ERR_INTERNAL;
     if (e->fault_tick && ++e->ticks_seen == e->fault_tick) return MM_ERR_INTERNAL;   // test hook: a tick that dies after its walk
     if ((size_t)total * M.L > (size_t)cfg.capacity + (size_t)MM_MAX_LOBBY * G) return MM_ERR_INTERNAL;
-    e->r_group.resize(total);
-    // The match list, group-major emission order.  The slots go first, group by group, each followed by
-    // an event: while the rest is still on its way the host already does its part for the groups that
-    // arrived — ActiveUser.remove_user for the matched players (game-lobby/worker.ex:73-103).
-    uint32_t k = 0;
-    for (uint32_t g = 0; g < G; ++g) {
-        const uint32_t ng = e->h_chains[mode * G + g].n_out;
-        if (!ng) continue;
-        HIPCHK(e, hipMemcpyAsync(&e->h_rslots[(size_t)k * M.L], e->d_out_slots + (size_t)g * e->out_slot_stride,
-                                 (size_t)ng * M.L * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipEventRecord(e->ev_grp[g], e->stream));
-        k += ng;
-    }
-    k = 0;
-    for (uint32_t g = 0; g < G; ++g) {
-        const uint32_t ng = e->h_chains[mode * G + g].n_out;
-        if (!ng) continue;
-        HIPCHK(e, hipMemcpyAsync(&e->h_rscore[k], e->d_out_score + (size_t)g * e->out_rec_stride, ng * sizeof(float),
-                                 hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipMemcpyAsync(&e->h_rpass[k], e->d_out_pass + (size_t)g * e->out_rec_stride, ng * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, e->stream));
-        k += ng;
+    // The match list, group-major emission order.  Most of it left for the host while the walk was still running
+    // (results_send at every look at the chains); what the last kernels emitted follows now, and the host does its
+    // part for what has arrived meanwhile — ActiveUser.remove_user for the matched players (game-lobby/worker.ex:73-103).
+    {
+        uint32_t bf[MM_MAX_GROUPS], no[MM_MAX_GROUPS];
+        for (uint32_t g = 0; g < G; ++g) {
+            const ChainDev& c = e->h_chains[mode * G + g];
+            bf[g] = c.n_out * M.L;                                   // tight: the counts are final
+            no[g] = c.n_out;
+            if (e->r_based && (c.n_out < e->r_sent[g] || (unsigned long long)c.n_out * M.L > (unsigned long long)c.before + M.L))
+                return MM_ERR_INTERNAL;
+        }
+        if (!e->r_based) results_set_bases(e, bf, M.L);
+        int src = results_send(e, no, M.L, 1u);
+        if (src) return src;
     }
     const uint32_t nrel = e->h_counters[0];
     e->r_released.resize(nrel);
     if (nrel)
         HIPCHK(e, hipMemcpyAsync(e->r_released.data(), e->d_released, nrel * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    k = 0;
+    {
+        int src = results_absorb(e, M.L);
+        if (src) return src;
+    }
+    e->r_pre[0] = 0;
     for (uint32_t g = 0; g < G; ++g) {
-        const uint32_t ng = e->h_chains[mode * G + g].n_out;
-        if (!ng) continue;
-        for (uint32_t i = 0; i < ng; ++i) e->r_group[k + i] = g;
-        HIPCHK(e, hipEventSynchronize(e->ev_grp[g]));
-        for (size_t i = (size_t)k * M.L, ns = (size_t)(k + ng) * M.L; i < ns; ++i) e->h_state[e->h_rslots[i]] = MM_ST_FREE;
-        k += ng;
+        e->r_cnt[g] = e->h_chains[mode * G + g].n_out;
+        e->r_pre[g + 1u] = e->r_pre[g] + e->r_cnt[g];
     }
     HIPCHK(e, hipStreamSynchronize(e->stream));
     // ... and the slots the liveness filter released
@@ -2075,10 +2172,18 @@ extern "C" int mm_matches(mm_engine* e, uint32_t first, uint32_t count, uint32_t
         if (!e) return MM_ERR_INVALID_ARG;
         if (first > e->r_n || count > e->r_n - first) return MM_ERR_RANGE;
         if (count == 0) return MM_OK;
-        if (slots) memcpy(slots, &e->h_rslots[(size_t)first * e->r_L], (size_t)count * e->r_L * sizeof(uint32_t));
-        if (score) memcpy(score, &e->h_rscore[first], count * sizeof(float));
-        if (group) memcpy(group, &e->r_group[first], count * sizeof(uint32_t));
-        if (pass) memcpy(pass, &e->h_rpass[first], count * sizeof(uint32_t));
+        // emission index i of the tick = lobby i - r_pre[g] of group g, stored at r_base[g] + that (tick_impl)
+        const uint32_t L = e->r_L;
+        for (uint32_t g = 0; g < e->cfg.n_groups; ++g) {
+            const uint32_t lo = e->r_pre[g] > first ? e->r_pre[g] : first;
+            const uint32_t hi = e->r_pre[g + 1u] < first + count ? e->r_pre[g + 1u] : first + count;
+            if (hi <= lo) continue;
+            const size_t src = (size_t)e->r_base[g] + (lo - e->r_pre[g]), dst = lo - first, n = hi - lo;
+            if (slots) memcpy(slots + dst * L, &e->h_rslots[src * L], n * L * sizeof(uint32_t));
+            if (score) memcpy(score + dst, &e->h_rscore[src], n * sizeof(float));
+            if (pass) memcpy(pass + dst, &e->h_rpass[src], n * sizeof(uint32_t));
+            if (group) for (size_t i = 0; i < n; ++i) group[dst + i] = g;
+        }
         return MM_OK;
     } catch (const std::bad_alloc&) {
         return MM_ERR_OOM;
