@@ -965,6 +965,7 @@ struct mm_engine {
     uint32_t r_sent[MM_MAX_GROUPS];     // lobbies of the running tick already on their way / arrived
     uint32_t r_marked[MM_MAX_GROUPS];   // ... whose players' slots are FREE in h_state already
     bool r_based;
+    bool results_early;        // MM_RESULTS_EARLY=0: the whole match list after the walk (A/B)
     bool poisoned;             // a tick failed half way: everything but reset / restore / destroy answers MM_ERR_STATE
     uint32_t fault_tick;       // MM_DEBUG_FAIL_TICK=k: the k-th mm_tick of this engine fails after its walk (test hook)
     uint32_t ticks_seen;
@@ -1241,6 +1242,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* trb = getenv("MM_TEAM_REBUILD");
             e->team_rebuild = trb ? (uint32_t)strtoul(trb, NULL, 0) : 8u;   // 4 / 6 / 8 measured within 0.1 ms of each other, 16: +0.9 ms, every pass: +1.4 ms
             if (e->team_rebuild < 1u) e->team_rebuild = 1u;
+            const char* rse = getenv("MM_RESULTS_EARLY");
+            e->results_early = !(rse && rse[0] == '0');
             const char* tlt = getenv("MM_TEAM_LATE");
             // measured on cfg-3 (profiles/r03_ab_team_late.txt): 0: 12.99 ms, 3: 12.50, 6: 12.46, 12: 12.76, 20: 13.67, 40: 15.73 per tick —
             // a look-up costs the chaser ~5 us (dependent trips to memory at ~1.5 us each when seven workgroups are all
@@ -1740,13 +1743,13 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 compact |= pc.want_compact != 0;
                 longest = pc.m > longest ? pc.m : longest;
             }
-            // the lobbies emitted so far leave for the host while the next batch runs (the first look sizes the groups' regions)
+            // the lobbies emitted so far leave for the host while the next batch runs (the first look sizes the groups'
+            // regions); the copies are enqueued BEHIND the batch's launches: the device does not wait for the host's calls
+            uint32_t sent_no[MM_MAX_GROUPS];
             {
-                uint32_t bf[MM_MAX_GROUPS], no[MM_MAX_GROUPS];
-                for (uint32_t g = 0; g < G; ++g) { bf[g] = e->h_pchains[g].before; no[g] = e->h_pchains[g].fast ? e->h_pchains[g].n_out : 0u; }
+                uint32_t bf[MM_MAX_GROUPS];
+                for (uint32_t g = 0; g < G; ++g) { bf[g] = e->h_pchains[g].before; sent_no[g] = e->h_pchains[g].fast ? e->h_pchains[g].n_out : 0u; }
                 if (!e->r_based) results_set_bases(e, bf, M.L);
-                int src = results_send(e, no, M.L, MM_RESULTS_MIN_PAIR);
-                if (src) return src;
             }
             if (!tiled) break;
             // tile length of this batch: the smallest that keeps the longest chain within PK_TILES_MAX tiles (the
@@ -1791,6 +1794,10 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             }
 #undef TILE_LAUNCH
             HIPCHK(e, hipGetLastError());
+            // the device is busy with the batch: now the host takes what the last look's copies brought (slots released)
+            // and sends this look's lobbies after them
+            { int arc = results_absorb(e, M.L); if (arc) return arc; }
+            { int src = results_send(e, sent_no, M.L, e->results_early ? MM_RESULTS_MIN_PAIR : 0xFFFFFFFFu); if (src) return src; }
         }
     }
     hipLaunchKernelGGL(kp_late, dim3(G), dim3(PL_THREADS), 0, e->stream, P);
@@ -1869,6 +1876,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     // lobbies and is over after two passes); once every chain that is still walked emits at most `team_late` lobbies
     // per pass, kt_late walks them to their end in one launch (mm_team.inc).
     uint32_t pass = 0, batch = e->team_batch < 2u ? e->team_batch : 2u;
+    uint32_t team_no[MM_MAX_GROUPS];
+    bool team_have = false;
     for (uint32_t guard = 0;; ++guard) {
         // a pass that changes nothing ends a chain and every other pass seats somebody
         if (guard > cfg.capacity + 64u) return MM_ERR_INTERNAL;
@@ -1887,6 +1896,9 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         }
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipMemcpyAsync(e->h_tchains, e->d_tchains, G * sizeof(TeamChain), hipMemcpyDeviceToHost, e->stream));
+        // host work while the device runs the batch: what the last look's copies brought, then this look's lobbies
+        { int arc = results_absorb(e, M.L); if (arc) return arc; }
+        if (team_have) { int src = results_send(e, team_no, M.L, e->results_early ? MM_RESULTS_MIN_TEAM : 0xFFFFFFFFu); if (src) return src; }
         HIPCHK(e, hipStreamSynchronize(e->stream));
         bool busy = false, late = e->team_late != 0u;
         uint32_t most = 0;
@@ -1908,12 +1920,11 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             e->dbg_last_w = tc.dbg[5];
             e->dbg_last_c = tc.dbg[4];
         }
-        {   // the lobbies emitted so far leave for the host while the next passes run
-            uint32_t bf[MM_MAX_GROUPS], no[MM_MAX_GROUPS];
-            for (uint32_t g = 0; g < G; ++g) { bf[g] = e->h_tchains[g].before; no[g] = e->h_tchains[g].fast ? e->h_tchains[g].n_out : 0u; }
+        {   // the lobbies emitted so far leave for the host while the next passes run (sent behind the next batch's launches)
+            uint32_t bf[MM_MAX_GROUPS];
+            for (uint32_t g = 0; g < G; ++g) { bf[g] = e->h_tchains[g].before; team_no[g] = e->h_tchains[g].fast ? e->h_tchains[g].n_out : 0u; }
             if (!e->r_based) results_set_bases(e, bf, M.L);
-            int src = results_send(e, no, M.L, MM_RESULTS_MIN_TEAM);
-            if (src) return src;
+            team_have = true;
         }
         if (!busy) break;
         if (late) {
