@@ -916,6 +916,9 @@ struct mm_engine {
     bool pair_fused;           // MM_PAIR_FUSED=0: three launches per round instead of one (A/B testing)
     uint32_t round_ctr;
     uint32_t* d_pk_tilectl;
+    uint4* d_pk_grec;          // second level of the route (kp_group)
+    uint32_t pk_gstride;
+    uint32_t pair_group_min;   // MM_PAIR_GROUP: tiles of the longest chain from which a batch runs with the second level (0 = never)
     PairChain* h_pchains;      // pinned
     uint32_t pk_bits_stride, pk_max_tiles, pk_stride;
     uint32_t pair_batch;       // MM_PAIR_BATCH: tiled rounds launched per host look at the chains
@@ -1163,6 +1166,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_pk_rec1);
     for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); }
     (void)hipFree(e->d_pk_tilectl);
+    (void)hipFree(e->d_pk_grec);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_tchains) (void)hipHostFree(e->h_tchains);
     if (e->h_rslots) (void)hipHostFree(e->h_rslots);
@@ -1228,6 +1232,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_tile_fixed = ptl && ptl[0] == 'm';
             const char* ptm = getenv("MM_PAIR_TILES");
             e->pair_tiles_max = ptm && atoi(ptm) > 0 ? (uint32_t)atoi(ptm) : PK_TILES_MAX;
+            const char* pgm = getenv("MM_PAIR_GROUP");
+            e->pair_group_min = pgm ? (uint32_t)strtoul(pgm, NULL, 0) : PK_GROUP_MIN;
             const char* pf = getenv("MM_PAIR_FUSED");
             e->pair_fused = !(pf && pf[0] == '0');
             e->round_ctr = 0;
@@ -1313,6 +1319,11 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             }
             CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
+            // two tiles' worth of entries per group of PK_GS tiles, whatever the tile length of the batch
+            e->pk_gstride = (uint32_t)(2u * (e->pk_stride / PK_GS) + 4u * PK_TMAX);
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_grec, (size_t)cfg->n_groups * e->pk_gstride * sizeof(uint4)));
+            // an entry carries the round it was made in (the walk takes one of its own round only): no stamp to start with
+            CREATE_CHK(hipMemsetAsync(e->d_pk_grec, 0xFF, (size_t)cfg->n_groups * e->pk_gstride * sizeof(uint4), e->stream));
             CREATE_CHK(hipHostMalloc((void**)&e->h_pchains, cfg->n_groups * sizeof(PairChain), hipHostMallocDefault));
             // a tick emits at most (cap + lobby) / 2 lobbies per group, cap + lobbies-in-progress players overall
             // (+ one lobby of slack per group: a group's region is sized by the players it holds when the tick begins)
@@ -1711,6 +1722,9 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     for (int b = 0; b < 2; ++b) { P.exa[b] = e->d_pk_exa[b]; P.bitsp[b] = e->d_pk_bitsp[b]; P.headp[b] = e->d_pk_headp[b]; }
     P.tilectl = e->d_pk_tilectl;
     P.max_tiles = e->pk_max_tiles;
+    P.grec = e->d_pk_grec;
+    P.gstride = e->pk_gstride;
+    P.grp = 0;
     P.out_slots = e->d_out_slots;
     P.out_score = e->d_out_score;
     P.out_pass = e->d_out_pass;
@@ -1777,11 +1791,18 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             if (e->pair_fused) {
                 // one launch per pass; the first of a batch only prepares, the commit brings the
                 // latest parity back into the chains' committed state
+                // chains of many tiles: a second level of the route, rebuilt behind every round (kp_group)
+                P.grp = (e->pair_group_min && tiles >= e->pair_group_min) ? PK_GS : 0u;
+                const uint32_t ngr = P.grp ? (tiles + P.grp - 1u) / P.grp : 0u;
                 uint32_t r = e->round_ctr;
                 TILE_LAUNCH(kp_round, dim3(tiles, G), dim3(PT_THREADS), P, r, 1u);
                 ++r;
-                for (uint32_t b = 0; b < e->pair_batch; ++b, ++r)
+                if (P.grp) TILE_LAUNCH(kp_group, dim3(ngr, G), dim3(1024), P, r);
+                for (uint32_t b = 0; b < e->pair_batch; ++b) {
                     TILE_LAUNCH(kp_round, dim3(tiles, G), dim3(PT_THREADS), P, r, 0u);
+                    ++r;
+                    if (P.grp) TILE_LAUNCH(kp_group, dim3(ngr, G), dim3(1024), P, r);
+                }
                 TILE_LAUNCH(kp_round_commit, dim3(tiles, G), dim3(256), P, r);
                 hipLaunchKernelGGL(kp_round_stage, dim3(G), dim3(64), 0, e->stream, P, r);
                 e->round_ctr = r;
@@ -2063,8 +2084,8 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
         std::vector<PairChain> hp(G);
         HIPCHK(e, hipMemcpy(hp.data(), e->d_pchains, G * sizeof(PairChain), hipMemcpyDeviceToHost));
         for (uint32_t g = 0; g < G; ++g)
-            fprintf(stderr, "[mm-pair] g%u fast %u m %u qlen %u passes %u out %u rounds %u | stale %u inv %u slowsucc %u compact %u fixed(w1) %u | chase clk %u wall(100MHz) %u wrapscan clk %u\n",
-                    g, hp[g].fast, hp[g].m, hp[g].qlen, hp[g].passes, hp[g].n_out, hp[g].rounds, hp[g].dbg[0], hp[g].dbg[1],
+            fprintf(stderr, "[mm-pair] g%u fast %u m %u qlen %u passes %u out %u rounds %u (group hops of tile 0: %u of %u entries looked at, %u not of the round) | stale %u inv %u slowsucc %u compact %u fixed(w1) %u | chase clk %u wall(100MHz) %u wrapscan clk %u\n",
+                    g, hp[g].fast, hp[g].m, hp[g].qlen, hp[g].passes, hp[g].n_out, hp[g].rounds, hp[g].ghops, hp[g].gtry, hp[g].gstale, hp[g].dbg[0], hp[g].dbg[1],
                     hp[g].dbg[2], hp[g].dbg[3], hp[g].dbg[4], hp[g].dbg[5], hp[g].dbg[6], hp[g].dbg[7]);
         for (uint32_t g = 0; g < G; ++g)
             if (hp[g].rounds) {

@@ -42,6 +42,16 @@ static __device__ __forceinline__ void tw_sload2_v(const uint32_t* p0, const uin
     tw_sload2(tw_sptr(p0), tw_sptr(p1), v0, v1);
 }
 
+// a 16-byte aligned record of four dwords, address wave-uniform (any register class)
+static __device__ __forceinline__ void tw_sload4_v(const uint32_t* p, uint32_t& v0, uint32_t& v1, uint32_t& v2, uint32_t& v3)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    const uint32_t* const sp = tw_sptr(p);
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(sp) : "memory");
+    v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+}
+
 // which of the eight XCDs this wave runs on (diagnostics: workgroup -> XCD placement is observed, not promised)
 static __device__ __forceinline__ uint32_t mm_xcc_id()
 {
