@@ -945,6 +945,8 @@ struct mm_engine {
     uint32_t team_batch;       // MM_TEAM_BATCH: passes launched per host look at the chains
     uint32_t team_cap;         // MM_TEAM_CAP: TeamParams.scan_cap
     uint32_t team_late;        // MM_TEAM_LATE: lobbies per pass at or under which kt_late takes the chains over (0 = never)
+    uint32_t team_late0;       // MM_TEAM_LATE0: arrivals of a mode since its last tick at or under which kt_late walks the tick from its first pass
+    std::vector<uint32_t> tk_last_len;   // [chain] queue + stored lobby after the chain's last tick (what a quiescent tick left)
     uint32_t dbg_last_w, dbg_last_c;   // MM_PAIR_DEBUG + MM_TEAM_BATCH=1: per-pass deltas of the F counters
     // host
     ChainDev* h_chains;        // pinned, n_chains
@@ -1248,6 +1250,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* trb = getenv("MM_TEAM_REBUILD");
             e->team_rebuild = trb ? (uint32_t)strtoul(trb, NULL, 0) : 8u;   // 4 / 6 / 8 measured within 0.1 ms of each other, 16: +0.9 ms, every pass: +1.4 ms
             if (e->team_rebuild < 1u) e->team_rebuild = 1u;
+            const char* tl0 = getenv("MM_TEAM_LATE0");
+            e->team_late0 = tl0 ? (uint32_t)strtoul(tl0, NULL, 0) : 512u;
+            e->tk_last_len.assign(e->n_chains, 0u);
             const char* rse = getenv("MM_RESULTS_EARLY");
             e->results_early = !(rse && rse[0] == '0');
             const char* tlt = getenv("MM_TEAM_LATE");
@@ -1386,6 +1391,7 @@ extern "C" int mm_reset(mm_engine* e)
         e->cancel_pending = 0;
         e->r_n = 0;
         e->live_upper = 0;
+        std::fill(e->tk_last_len.begin(), e->tk_last_len.end(), 0u);
         const int rc = engine_reset_device(e);
         if (rc == MM_OK) e->poisoned = false;
         return rc;
@@ -1455,6 +1461,7 @@ static int ring_range_free(const mm_engine* e, uint32_t n)
 {
     const uint32_t cap = e->cfg.capacity;
     if (n > cap) return 0;
+    if (e->live_upper == 0) return 1;           // nobody queued, seated or cancelled-and-not-yet-purged: every slot is free
     const uint32_t a = e->next_slot;
     const uint32_t n1 = n < cap - a ? n : cap - a;
     if (n1 && memchr(&e->h_state[a], MM_ST_LIVE, n1)) return 0;
@@ -1853,6 +1860,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     P.released = e->d_released;
     P.n_released = e->d_counters;
     P.scan_cap = e->team_cap;
+    P.late_bail = 4u * e->team_late + 32u;
     P.debug = e->pair_debug ? 1u : 0u;
     P.M = M;
     P.chains = e->d_chains;
@@ -1884,8 +1892,16 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     HIPCHK(e, hipMemcpyAsync(e->h_tchains, e->d_tchains, G * sizeof(TeamChain), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     uint32_t longest = 0;
-    for (uint32_t g = 0; g < G; ++g)
-        if (e->h_tchains[g].fast && e->h_tchains[g].m > longest) longest = e->h_tchains[g].m;
+    unsigned long long arrivals = 0;
+    bool late_ok = e->team_late != 0u;
+    for (uint32_t g = 0; g < G; ++g) {
+        const TeamChain& t = e->h_tchains[g];
+        if (!t.fast) continue;
+        if (t.m > longest) longest = t.m;
+        const uint32_t had = e->tk_last_len[mode * G + g];
+        arrivals += t.before > had ? t.before - had : 0u;
+        if (t.m > TL_BITS_MAX || t.sitout) late_ok = false;      // (a head that sat out is not in the first pass's sub-queues)
+    }
     if (!longest) return MM_OK;
     *any = true;
     const uint32_t nch = (longest + TT_CH - 1u) / TT_CH;
@@ -1895,42 +1911,66 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     HIPCHK(e, hipGetLastError());
     // Batches of passes between two looks at the chains.  The first is short (a tick of a stream seats a handful of
     // lobbies and is over after two passes); once every chain that is still walked emits at most `team_late` lobbies
-    // per pass, kt_late walks them to their end in one launch (mm_team.inc).
+    // per pass, kt_late walks them to their end in one launch (mm_team.inc) — from the first pass on when the mode has
+    // seen only a few arrivals since its last (quiescent) tick: the ticks of a stream.  kt_late hands a chain back
+    // after a pass that seated many lobbies after all (`late_bail`); the sub-queues are rebuilt then (it leaves no
+    // tombstones behind).
     uint32_t pass = 0, batch = e->team_batch < 2u ? e->team_batch : 2u;
     uint32_t team_no[MM_MAX_GROUPS];
-    bool team_have = false;
+    bool team_have = false, force_build = false;
+    bool late_now = late_ok && e->team_late0 != 0u && arrivals <= e->team_late0;
+    if (late_now) hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
     for (uint32_t guard = 0;; ++guard) {
         // a pass that changes nothing ends a chain and every other pass seats somebody
         if (guard > cfg.capacity + 64u) return MM_ERR_INTERNAL;
-        for (uint32_t b = 0; b < batch; ++b, ++pass) {
-            // the first passes of a tick emit hundreds of lobbies each: the chase takes them two at a time (kt_f2)
-            P.use_f2 = pass < e->team_f2 ? 1u : 0u;
-            // the role sub-queues are rebuilt in the first two passes (a head that sat out the first one is back in
-            // the second) and every team_rebuild passes after; in between, players that leave are tombstones in them
-            if (pass < 2u || pass % e->team_rebuild == 0u)
-                hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
-            hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
-            if (P.use_f2) hipLaunchKernelGGL(kt_f2, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
-            if (P.use_f2) hipLaunchKernelGGL(kt_chase<1>, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
-            else hipLaunchKernelGGL(kt_chase<0>, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
-            hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
+        if (late_now) {
+            hipLaunchKernelGGL(kt_late, dim3(G), dim3(TL_THREADS), 0, e->stream, P);
+            force_build = true;                       // whoever comes back from kt_late needs fresh sub-queues
+        } else {
+            for (uint32_t b = 0; b < batch; ++b, ++pass) {
+                // the first passes of a tick emit hundreds of lobbies each: the chase takes them two at a time (kt_f2)
+                P.use_f2 = pass < e->team_f2 ? 1u : 0u;
+                // the role sub-queues are rebuilt in the first two passes (a head that sat out the first one is back in
+                // the second) and every team_rebuild passes after; in between, players that leave are tombstones in them
+                if (pass < 2u || pass % e->team_rebuild == 0u || force_build)
+                    hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+                force_build = false;
+                hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+                if (P.use_f2) hipLaunchKernelGGL(kt_f2, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+                if (P.use_f2) hipLaunchKernelGGL(kt_chase<1>, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
+                else hipLaunchKernelGGL(kt_chase<0>, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
+                hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
+            }
         }
         HIPCHK(e, hipGetLastError());
+        uint32_t p0[MM_MAX_GROUPS];
+        for (uint32_t g = 0; g < G; ++g) p0[g] = e->h_tchains[g].passes;
         HIPCHK(e, hipMemcpyAsync(e->h_tchains, e->d_tchains, G * sizeof(TeamChain), hipMemcpyDeviceToHost, e->stream));
         // host work while the device runs the batch: what the last look's copies brought, then this look's lobbies
         { int arc = results_absorb(e, M.L); if (arc) return arc; }
         if (team_have) { int src = results_send(e, team_no, M.L, e->results_early ? MM_RESULTS_MIN_TEAM : 0xFFFFFFFFu); if (src) return src; }
         HIPCHK(e, hipStreamSynchronize(e->stream));
-        bool busy = false, late = e->team_late != 0u;
+        bool busy = false, late = late_ok;
         uint32_t most = 0;
         for (uint32_t g = 0; g < G; ++g) {
             const TeamChain& t = e->h_tchains[g];
             if (!t.fast || t.done) continue;
             busy = true;
             most = t.n_vis > most ? t.n_vis : most;
-            if (t.n_vis > e->team_late || t.m > TL_BITS_MAX) late = false;
+            if (t.n_vis > e->team_late) late = false;
         }
-        if (e->pair_debug && e->team_batch == 1u) {   // MM_TEAM_BATCH=1: one line per pass, the longest chain
+        if (e->pair_debug && late_now)
+            for (uint32_t g = 0; g < G; ++g) {
+                const TeamChain& t = e->h_tchains[g];
+                if (t.fast && t.passes != p0[g])
+                    fprintf(stderr, "[mm-team-late] g%u: kt_late walked passes %u..%u%s (m %u, sub-queues %u %u %u %u %u): "
+                            "%u lobbies by record, %u looked up, %u left open, %u stored fills; entries scanned per role %u %u %u %u %u; "
+                            "cycles/16: records %u look-ups %u fills %u ring waits %u all %u\n", g, p0[g], t.passes,
+                            t.done ? "" : " and handed the chain back", t.m, t.len[0], t.len[1], t.len[2], t.len[3], t.len[4],
+                            t.lt[1], t.lt[2], t.lt[3], t.lt[4], t.lt[5], t.lt[6], t.lt[7], t.lt[8], t.lt[9], t.lt[10], t.lt[11],
+                            t.lt[12], t.lt[14], t.lt[13]);
+            }
+        if (e->pair_debug && e->team_batch == 1u && !late_now) {   // MM_TEAM_BATCH=1: one line per pass, the longest chain
             uint32_t gl = 0;
             for (uint32_t g = 1; g < G; ++g)
                 if (e->h_tchains[g].m > e->h_tchains[gl].m) gl = g;
@@ -1948,27 +1988,15 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             team_have = true;
         }
         if (!busy) break;
-        if (late) {
-            hipLaunchKernelGGL(kt_late, dim3(G), dim3(TL_THREADS), 0, e->stream, P);
-            HIPCHK(e, hipGetLastError());
-            if (e->pair_debug) {
-                uint32_t p0[MM_MAX_GROUPS];
-                for (uint32_t g = 0; g < G; ++g) p0[g] = e->h_tchains[g].passes;
-                HIPCHK(e, hipMemcpyAsync(e->h_tchains, e->d_tchains, G * sizeof(TeamChain), hipMemcpyDeviceToHost, e->stream));
-                HIPCHK(e, hipStreamSynchronize(e->stream));
-                for (uint32_t g = 0; g < G; ++g)
-                    if (e->h_tchains[g].fast && e->h_tchains[g].passes != p0[g])
-                    {
-                        const TeamChain& t = e->h_tchains[g];
-                        fprintf(stderr, "[mm-team-late] g%u: kt_late walked passes %u..%u (%u lobbies at the switch; m %u, sub-queues %u %u %u %u %u): "
-                                "%u lobbies by record, %u looked up, %u left open, %u stored fills; entries scanned per role %u %u %u %u %u; "
-                                "cycles/16: records %u look-ups %u fills %u ring waits %u all %u\n", g, p0[g], t.passes, most, t.m,
-                                t.len[0], t.len[1], t.len[2], t.len[3], t.len[4], t.lt[1], t.lt[2], t.lt[3], t.lt[4],
-                                t.lt[5], t.lt[6], t.lt[7], t.lt[8], t.lt[9], t.lt[10], t.lt[11], t.lt[12], t.lt[14], t.lt[13]);
-                    }
-            }
-            break;
+        if (late_now) {
+            // a chain came back from kt_late (a pass seated more than late_bail lobbies): the pass kernels take over,
+            // from the chain's current pass on
+            late_now = false;
+            if (pass < 2u) pass = 2u;                 // (no doubled rebuild: the tick is past its opening)
+            batch = e->team_batch;
+            continue;
         }
+        late_now = late;
         // close to the switch: look again soon (a look costs a D2H round trip, an idle pass three launches)
         batch = (e->team_late && most <= 3u * e->team_late) ? (e->team_batch < 4u ? e->team_batch : 4u) : e->team_batch;
     }
@@ -2163,6 +2191,7 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     }
     e->r_pre[0] = 0;
     for (uint32_t g = 0; g < G; ++g) {
+        e->tk_last_len[mode * G + g] = e->h_chains[mode * G + g].len + e->h_chains[mode * G + g].lobby.n;
         e->r_cnt[g] = e->h_chains[mode * G + g].n_out;
         e->r_pre[g + 1u] = e->r_pre[g] + e->r_cnt[g];
     }

@@ -183,13 +183,17 @@ def test_team_path_on_a_starving_stream(oracle_cls):
     assert depth.min() >= 64 and sum(per) > 0
 
 
-@pytest.mark.parametrize("late", ["0", "1000"])
-def test_kt_late_takes_the_chains_over_at_any_point(oracle_cls, monkeypatch, late):
+@pytest.mark.parametrize("late,late0", [("0", "512"), ("1000", "512"), ("1", "10000000"), ("6", "10000000")])
+def test_kt_late_takes_the_chains_over_at_any_point(oracle_cls, monkeypatch, late, late0):
     """kt_late (one persistent workgroup per chain for the passes that seat a handful of lobbies) must give the pass
     kernels' results wherever the hand-over happens: MM_TEAM_LATE=1000 hands every chain over after the first batch
-    (two passes), 0 never does.  Cancel ticks, stored lobbies and the starving stream included."""
+    (two passes), 0 never does; MM_TEAM_LATE0 = arrivals since the mode's last tick up to which kt_late walks a tick from
+    its FIRST pass — with 10^7 every tick starts there, and the big first ticks make it hand the chains back after a pass
+    that seated more than 4 x MM_TEAM_LATE + 32 lobbies (the pass kernels go on behind a rebuild of the sub-queues).
+    Cancel ticks, stored lobbies and the starving stream included."""
     from helpers import run_starving_team_stream
     monkeypatch.setenv("MM_TEAM_LATE", late)
+    monkeypatch.setenv("MM_TEAM_LATE0", late0)
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=3, weights=W5) > 50
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=4, regions=2) > 50
     per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=8, per_tick=80, cancels=9,
@@ -199,3 +203,13 @@ def test_kt_late_takes_the_chains_over_at_any_point(oracle_cls, monkeypatch, lat
     rng = np.random.default_rng(5)
     with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
         random_scenario(rng, cfg, a, b, n_rounds=4, batch=1500, cancel_frac=0.05)
+
+
+def test_kt_late_hands_a_chain_back_after_a_rich_pass(oracle_cls, monkeypatch):
+    """kt_late from the first pass (MM_TEAM_LATE0) on a pool whose first pass seats more lobbies than `late_bail`
+    (4 x MM_TEAM_LATE + 32): it stops at the pass boundary, the sub-queues are rebuilt (kt_late leaves no tombstones)
+    and the pass kernels finish the tick — same lobbies, order, counters and state as the oracle's."""
+    monkeypatch.setenv("MM_TEAM_LATE", "1")
+    monkeypatch.setenv("MM_TEAM_LATE0", "10000000")
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 12000, seed=9, n_ticks=2,
+                 weights=[0.2] * 5, capacity=1 << 15) > 300
