@@ -918,6 +918,7 @@ struct mm_engine {
     uint32_t* d_pk_tilectl;
     uint4* d_pk_grec;          // second level of the route (kp_group)
     uint32_t pk_gstride;
+    bool pair_xcd;             // MM_PAIR_XCD=0: kp_round on the plain (tile, group) grid (A/B)
     uint32_t pair_group_min;   // MM_PAIR_GROUP: tiles of the longest chain from which a batch runs with the second level (0 = never)
     PairChain* h_pchains;      // pinned
     uint32_t pk_bits_stride, pk_max_tiles, pk_stride;
@@ -1234,6 +1235,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_tile_fixed = ptl && ptl[0] == 'm';
             const char* ptm = getenv("MM_PAIR_TILES");
             e->pair_tiles_max = ptm && atoi(ptm) > 0 ? (uint32_t)atoi(ptm) : PK_TILES_MAX;
+            const char* pxc = getenv("MM_PAIR_XCD");
+            e->pair_xcd = !(pxc && pxc[0] == '0');
             const char* pgm = getenv("MM_PAIR_GROUP");
             e->pair_group_min = pgm ? (uint32_t)strtoul(pgm, NULL, 0) : PK_GROUP_MIN;
             const char* pf = getenv("MM_PAIR_FUSED");
@@ -1690,6 +1693,61 @@ static int results_send(mm_engine* e, const uint32_t* n_out, uint32_t L, uint32_
     return MM_OK;
 }
 
+// kp_round's workgroup map of a batch (PairParams.xseg): the tiles of a chain on as few XCDs as its tile count allows.
+// Up to eight chains: an XCD each, the XCDs that are left go one by one to the chain with the most tiles per XCD;
+// more chains than XCDs: longest first onto the emptiest XCD.  Returns the slots per XCD (0: no map, the plain grid).
+static uint32_t pair_xcd_map(PairParams& P, const uint32_t* tiles_of, uint32_t G)
+{
+    memset(P.xseg, 0, sizeof(P.xseg));
+    memset(P.xcnt, 0, sizeof(P.xcnt));
+    P.xslots = 0;
+    uint32_t order[MM_MAX_GROUPS], n = 0;
+    for (uint32_t g = 0; g < G; ++g)
+        if (tiles_of[g]) order[n++] = g;
+    if (!n) return 0;
+    std::sort(order, order + n, [&](uint32_t a, uint32_t b) { return tiles_of[a] != tiles_of[b] ? tiles_of[a] > tiles_of[b] : a < b; });
+    uint32_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nseg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n <= 8u) {
+        uint32_t k[MM_MAX_GROUPS];
+        for (uint32_t i = 0; i < n; ++i) k[i] = 1;
+        for (uint32_t spare = 8u - n; spare; --spare) {
+            uint32_t best = 0;
+            for (uint32_t i = 1; i < n; ++i)
+                if ((unsigned long long)tiles_of[order[i]] * k[best] > (unsigned long long)tiles_of[order[best]] * k[i]) best = i;
+            if (tiles_of[order[best]] <= k[best]) break;            // a tile per XCD already
+            ++k[best];
+        }
+        uint32_t x = 0;
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t j = 0; j < k[i]; ++j, ++x) {
+                const uint32_t g = order[i], cnt = (tiles_of[g] - j + k[i] - 1u) / k[i];
+                if (k[i] > 255u || cnt > 0xFFFFu) return 0;
+                P.xseg[x][0] = g | (j << 8) | (k[i] << 16);
+                P.xcnt[x][0] = (uint16_t)cnt;
+                load[x] = cnt;
+            }
+    } else {
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t x = 0;
+            for (uint32_t y = 1; y < 8u; ++y)
+                if (load[y] < load[x]) x = y;
+            const uint32_t g = order[i];
+            if (nseg[x] >= PK_XSEG || tiles_of[g] > 0xFFFFu) return 0;
+            P.xseg[x][nseg[x]] = g | (0u << 8) | (1u << 16);
+            P.xcnt[x][nseg[x]] = (uint16_t)tiles_of[g];
+            ++nseg[x];
+            load[x] += tiles_of[g];
+        }
+    }
+    uint32_t slots = 0;
+    for (uint32_t x = 0; x < 8u; ++x) slots = load[x] > slots ? load[x] : slots;
+    // a workgroup per CU (32 CUs an XCD): with more, the XCD that holds a long chain alone would run its workgroups in
+    // several waves while others idle — big pools stay on the plain grid, which spreads every chain over all XCDs
+    if (slots > 32u) { memset(P.xseg, 0, sizeof(P.xseg)); memset(P.xcnt, 0, sizeof(P.xcnt)); return 0; }
+    P.xslots = slots;
+    return slots;
+}
+
 // The pair path (mm_pair.inc) for every chain of `mode` it is eligible for; the others are
 // left to k_walk (PairChain.fast == 0).  All launches are asynchronous on the engine stream.
 static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
@@ -1801,12 +1859,21 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 // chains of many tiles: a second level of the route, rebuilt behind every round (kp_group)
                 P.grp = (e->pair_group_min && tiles >= e->pair_group_min) ? PK_GS : 0u;
                 const uint32_t ngr = P.grp ? (tiles + P.grp - 1u) / P.grp : 0u;
+                // the batch's workgroup map: a chain's tiles together on one XCD (mm_pair.inc, PairParams.xseg)
+                dim3 rgrid(tiles, G);
+                P.xslots = 0;
+                if (e->pair_xcd) {
+                    uint32_t tof[MM_MAX_GROUPS];
+                    for (uint32_t g = 0; g < G; ++g) tof[g] = P.bm[g] ? (P.bm[g] + tp - 1u) / tp : 0u;
+                    const uint32_t slots = pair_xcd_map(P, tof, G);
+                    if (slots) rgrid = dim3(8u * slots);
+                }
                 uint32_t r = e->round_ctr;
-                TILE_LAUNCH(kp_round, dim3(tiles, G), dim3(PT_THREADS), P, r, 1u);
+                TILE_LAUNCH(kp_round, rgrid, dim3(PT_THREADS), P, r, 1u);
                 ++r;
                 if (P.grp) TILE_LAUNCH(kp_group, dim3(ngr, G), dim3(1024), P, r);
                 for (uint32_t b = 0; b < e->pair_batch; ++b) {
-                    TILE_LAUNCH(kp_round, dim3(tiles, G), dim3(PT_THREADS), P, r, 0u);
+                    TILE_LAUNCH(kp_round, rgrid, dim3(PT_THREADS), P, r, 0u);
                     ++r;
                     if (P.grp) TILE_LAUNCH(kp_group, dim3(ngr, G), dim3(1024), P, r);
                 }
