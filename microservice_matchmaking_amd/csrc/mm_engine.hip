@@ -1857,7 +1857,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 // one launch per pass; the first of a batch only prepares, the commit brings the
                 // latest parity back into the chains' committed state
                 // chains of many tiles: a second level of the route, rebuilt behind every round (kp_group)
-                P.grp = (e->pair_group_min && tiles >= e->pair_group_min) ? PK_GS : 0u;
+                P.grp = (e->pair_group_min && tiles >= e->pair_group_min && tp == PK_TMAX) ? PK_GS : 0u;
                 const uint32_t ngr = P.grp ? (tiles + P.grp - 1u) / P.grp : 0u;
                 // the batch's workgroup map: a chain's tiles together on one XCD (mm_pair.inc, PairParams.xseg)
                 dim3 rgrid(tiles, G);
