@@ -40,6 +40,8 @@
 #include <string.h>
 #include <time.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <new>
@@ -977,6 +979,38 @@ struct mm_engine {
     uint32_t ticks_seen;
 };
 
+// Named ranges for a profiler's timeline (the reference logs nothing per attempt).  MM_ROCTX=1 makes
+// every engine of the process mark its enqueue / tick phases with roctxRangePush / Pop, resolved at run time from
+// librocprofiler-sdk-roctx.so or libroctx64.so — no link-time dependency, nothing at all when the variable is unset.
+struct RoctxApi {
+    int (*push)(const char*);
+    int (*pop)(void);
+    bool tried;
+};
+static RoctxApi g_roctx = { nullptr, nullptr, false };
+static void roctx_init(void)
+{
+    if (g_roctx.tried) return;
+    g_roctx.tried = true;
+    const char* on = getenv("MM_ROCTX");
+    if (!on || on[0] != '1') return;
+    static const char* const libs[] = { "librocprofiler-sdk-roctx.so", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so.4" };
+    for (unsigned i = 0; i < sizeof(libs) / sizeof(libs[0]) && !g_roctx.push; ++i) {
+        void* h = dlopen(libs[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        g_roctx.pop = (int (*)(void))dlsym(h, "roctxRangePop");
+        if (!g_roctx.push || !g_roctx.pop) { g_roctx.push = nullptr; g_roctx.pop = nullptr; }
+    }
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(g_roctx.push != nullptr) { if (on) (void)g_roctx.push(name); }
+    ~RoctxRange() { if (on) (void)g_roctx.pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 static double host_now_ms(void)
 {
     struct timespec ts;
@@ -1208,6 +1242,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
             return MM_ERR_NO_DEVICE;
+        roctx_init();
         mm_engine* e = new (std::nothrow) mm_engine();
         if (!e) return MM_ERR_OOM;
         e->cfg = *cfg;
@@ -1503,6 +1538,7 @@ extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const
         if (!e || (n && (!rating || !cons))) return MM_ERR_INVALID_ARG;
         if (e->poisoned) return MM_ERR_STATE;
         ON_ENGINE_DEVICE(e);
+        RoctxRange rr("mm_enqueue");
         const double t0 = host_now_ms();
         if (st) memset(st, 0, sizeof(*st));
         if (n == 0) return MM_OK;
@@ -2114,6 +2150,7 @@ extern "C" int mm_tick(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stat
 
 static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats* stats)
 {
+    RoctxRange rr_tick("mm_tick");
     const double t0 = host_now_ms();
     const mm_config& cfg = e->cfg;
     const uint32_t G = cfg.n_groups;
@@ -2136,12 +2173,14 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     if (timing) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
     const bool use_pair = M.team_size == 1u && M.teams == 2u && !e->force_generic;
     if (use_pair) {
+        RoctxRange rr("mm_tick/pair walk");
         int prc = pair_walk(e, mode, M, purge);
         if (prc) return prc;
     }
     // team modes: long chains take the team path
     bool team_any = false;
     if (!use_pair && !e->force_generic && e->live_upper >= TT_MIN) {
+        RoctxRange rr("mm_tick/team walk");
         int trc = team_walk(e, mode, M, purge, &team_any);
         if (trc) return trc;
     }
@@ -2232,6 +2271,7 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     if (errf) return MM_ERR_INTERNAL;
     if (e->fault_tick && ++e->ticks_seen == e->fault_tick) return MM_ERR_INTERNAL;   // test hook: a tick that dies after its walk
     if ((size_t)total * M.L > (size_t)cfg.capacity + (size_t)MM_MAX_LOBBY * G) return MM_ERR_INTERNAL;
+    RoctxRange rr_res("mm_tick/match list");
     // The match list, group-major emission order.  Most of it left for the host while the walk was still running
     // (results_send at every look at the chains); what the last kernels emitted follows now, and the host does its
     // part for what has arrived meanwhile — ActiveUser.remove_user for the matched players (game-lobby/worker.ex:73-103).
