@@ -43,6 +43,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <new>
 #include <vector>
@@ -1163,6 +1164,32 @@ static ModeDev make_mode_dev(const mm_mode_config& mc)
     return M;
 }
 
+// ONE copy stream per device for all engines of the process: the runtime maps streams onto a few hardware queues
+// (four by default), and two engines with a second stream each had their main streams share a queue — two pools on
+// one GPU ran one after the other (concurrent_pools 152 -> 87 M matched players/s until this was shared).
+static std::mutex g_copy_mu;
+static hipStream_t g_copy_stream[64];
+static int g_copy_refs[64];
+static int copy_stream_acquire(int dev, hipStream_t* out)
+{
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    if (dev < 0 || dev >= 64) return 1;
+    if (g_copy_refs[dev] == 0 && hipStreamCreateWithFlags(&g_copy_stream[dev], hipStreamNonBlocking) != hipSuccess) return 1;
+    ++g_copy_refs[dev];
+    *out = g_copy_stream[dev];
+    return 0;
+}
+static void copy_stream_release(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    if (dev < 0 || dev >= 64 || g_copy_refs[dev] == 0) return;
+    if (--g_copy_refs[dev] == 0) {
+        (void)hipStreamSynchronize(g_copy_stream[dev]);
+        (void)hipStreamDestroy(g_copy_stream[dev]);
+        g_copy_stream[dev] = nullptr;
+    }
+}
+
 extern "C" void mm_engine_destroy(mm_engine* e)
 {
     if (!e) return;
@@ -1215,8 +1242,9 @@ extern "C" void mm_engine_destroy(mm_engine* e)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (uint32_t i = 0; i < MM_MAX_GROUPS; ++i)
         if (e->ev_grp[i]) (void)hipEventDestroy(e->ev_grp[i]);
+    if (e->ev_copy_pending) (void)hipEventSynchronize(e->ev_copy);     // (nothing of this engine is left on the shared stream)
+    if (e->copy_stream) { e->copy_stream = nullptr; copy_stream_release(e->cfg.device); }
     if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
-    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1321,7 +1349,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         for (int i = 0; i < 4; ++i) CREATE_CHK(hipEventCreate(&e->ev[i]));
         for (uint32_t i = 0; i < cfg->n_groups; ++i) CREATE_CHK(hipEventCreate(&e->ev_grp[i]));
-        CREATE_CHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        if (copy_stream_acquire(cfg->device, &e->copy_stream)) { e->copy_stream = nullptr; mm_engine_destroy(e); return MM_ERR_HIP; }
         CREATE_CHK(hipEventCreate(&e->ev_copy));
         e->ev_copy_pending = false;
         e->r_based = false;
