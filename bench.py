@@ -470,7 +470,8 @@ def main():
             def step():
                 eng.reset()
                 first = eng.enqueue_device(d_rating, d_cons)
-                return first, eng.tick(0), dict(eng.last_enqueue_stats)
+                # the match list lands in buffers the binding keeps (views valid until the next tick, as the ABI's list)
+                return first, eng.tick(0, reuse=True), dict(eng.last_enqueue_stats)
             for _ in range(warmup):
                 step()
         sync()

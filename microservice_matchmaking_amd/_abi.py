@@ -279,16 +279,29 @@ class EngineBase:
         slots = np.ascontiguousarray(slots, dtype=np.uint32)
         self._check(self._fn("cancel")(self._h, slots.shape[0], _ptr(slots)), "cancel")
 
-    def tick(self, mode=0) -> Matches:
+    def tick(self, mode=0, reuse=False) -> Matches:
+        """One tick.  reuse=True copies the match list into buffers the engine object keeps (grown as needed) and
+        returns VIEWS of them — valid until the next tick(reuse=True) on this object, like the ABI's own list
+        (mm_matches: "readable until the next mm_tick"); a caller that ticks every few milliseconds does not
+        want four fresh page-faulting arrays per tick."""
         n = C.c_uint32()
         st = MMStats()
         self._check(self._fn("tick")(self._h, mode, C.byref(n), C.byref(st)), "tick")
         n = int(n.value)
         L = self.lobby_size(mode)
-        slots = np.empty((n, L), dtype=np.uint32)
-        score = np.empty(n, dtype=np.float32)
-        group = np.empty(n, dtype=np.uint32)
-        pass_ = np.empty(n, dtype=np.uint32)
+        if reuse:
+            have = getattr(self, "_reuse", None)
+            if have is None or have[0].size < n * L or have[1].size < n:
+                cap = max(n, 1024)
+                have = (np.empty(cap * L, np.uint32), np.empty(cap, np.float32), np.empty(cap, np.uint32),
+                        np.empty(cap, np.uint32))
+                self._reuse = have
+            slots, score, group, pass_ = have[0][:n * L].reshape(n, L), have[1][:n], have[2][:n], have[3][:n]
+        else:
+            slots = np.empty((n, L), dtype=np.uint32)
+            score = np.empty(n, dtype=np.float32)
+            group = np.empty(n, dtype=np.uint32)
+            pass_ = np.empty(n, dtype=np.uint32)
         self._check(self._fn("matches")(self._h, 0, n, _ptr(slots), _ptr(score), _ptr(group),
                                         _ptr(pass_)), "matches")
         return Matches(slots, score, group, pass_, st.as_dict())

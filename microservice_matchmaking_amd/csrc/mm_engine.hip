@@ -2378,7 +2378,7 @@ extern "C" int mm_matches(mm_engine* e, uint32_t first, uint32_t count, uint32_t
             if (slots) memcpy(slots + dst * L, &e->h_rslots[src * L], n * L * sizeof(uint32_t));
             if (score) memcpy(score + dst, &e->h_rscore[src], n * sizeof(float));
             if (pass) memcpy(pass + dst, &e->h_rpass[src], n * sizeof(uint32_t));
-            if (group) for (size_t i = 0; i < n; ++i) group[dst + i] = g;
+            if (group) std::fill_n(group + dst, n, g);
         }
         return MM_OK;
     } catch (const std::bad_alloc&) {

@@ -77,9 +77,9 @@ class DryEngine(EmuEngine):
         with _SHIM_LOCK:
             return super().reset()
 
-    def tick(self, mode=0):
+    def tick(self, mode=0, reuse=False):
         with _SHIM_LOCK:
-            return super().tick(mode)
+            return super().tick(mode, reuse=reuse)
 
     def enqueue_device(self, d_rating, d_cons):
         from microservice_matchmaking_amd._abi import MMEnqueueStats
