@@ -507,11 +507,15 @@ def main():
                "exactness": {"emission_digest": union_digest(dg), "oracle_digest": want, "key": key}}
         if traffic_path:
             traffic, tnote = load_traffic(traffic_path, n, w["mode"])
-            out["roofline"] = roofline_block(w["mode"], float(l.stats["pairs"]), w["bytes_per_pair"], walk_ms, step_ms, n,
-                                             int(l.stats["passes_max"]), traffic, boundary_us, tnote)
+            # (the block itself is made at the end of the run, when the kernel boundary has been measured)
+            out["_roofline_args"] = (w["mode"], float(l.stats["pairs"]), w["bytes_per_pair"], walk_ms, step_ms, n,
+                                     int(l.stats["passes_max"]), traffic, tnote)
         return out
 
-    boundary_us = measure_boundary_us(torch) if (rank == 0 and not args.no_boundary) else None
+    # The kernel-boundary micro-measurement runs LAST (rank 0): it captures a graph on a side stream of torch's, and that
+    # stream stays alive in torch's pool — with it the process holds more streams than the runtime has hardware queues
+    # (four), two engines' streams end up sharing one and the concurrent_pools leg measures 87 instead of 152 M/s.
+    boundary_us = None
     tdefault = os.path.join(ROOT, "profiles",
                             "traffic_latest.json" if args.mode == "1v1" else "traffic_latest_%s.json" % args.mode)
 
@@ -586,9 +590,10 @@ def main():
             "passes_max": max(p["passes_max"] for p in parts),
             "kernel_ms": {"walk": slow["walk_ms"], "bucket(count+scan+scatter)": slow["bucket_ms"],
                           "d2h+bookkeeping": slow["copy_ms"], "of_rank": slow["rank"]},
-            "roofline": roofline_block(args.mode, pairs, wl["bytes_per_pair"], slow["walk_ms"], step_ms, n,
-                                       max(p["passes_max"] for p in parts), traffic, boundary_us, tnote),
+            "roofline": None,
         }
+        main_roofline_args = (args.mode, pairs, wl["bytes_per_pair"], slow["walk_ms"], step_ms, n,
+                              max(p["passes_max"] for p in parts), traffic, tnote)
         if world == 1 and not args.no_cpu_baseline:
             cfg_cpu = make_config(wl["modes"], capacity=pow2(n), device=local_rank, timing=False)
             line["cpu_baseline"] = cpu_baseline(cfg_cpu, rating, cons, args.mode, budget_s=args.cpu_baseline_seconds)
@@ -704,6 +709,15 @@ def main():
                     line["latency_mixed"] = res
 
     if rank == 0:
+        boundary_us = None if args.no_boundary else measure_boundary_us(torch)
+        a = main_roofline_args
+        line["roofline"] = roofline_block(*a[:8], boundary_us, a[8])
+        if "cfg3" in line and "_roofline_args" in line["cfg3"]:
+            a = line["cfg3"].pop("_roofline_args")
+            line["cfg3"]["roofline"] = roofline_block(*a[:8], boundary_us, a[8])
+        for leg in ("shared_pool_n1",):
+            if leg in line:
+                line[leg].pop("_roofline_args", None)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
