@@ -360,3 +360,54 @@ def test_gpu_randomised_stress_short(gpu_cls, monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr("sys.argv", ["gpu_stress.py", "10", "3"])
     mod.main()
+
+
+def test_gpu_pair_second_route_level_forced(gpu_cls, oracle_cls, monkeypatch):
+    """kp_group (the second level of the route, by default only for chains of 64+ tiles: the 10M pool) on every tiled
+    chain of a 300k pool — MM_PAIR_GROUP=4: groups at 8192-position tiles while the chains shrink through all the
+    batches that still use the longest tile — over three ticks with arrivals and cancels."""
+    monkeypatch.setenv("MM_PAIR_GROUP", "4")
+    cfg = make_config([mode_1v1(window=25, region_filter=True)], capacity=1 << 20)
+    rng = np.random.default_rng(12)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        live = np.zeros(0, np.uint32)
+        for tick in range(3):
+            rating, cons = make_pool(600000 if tick == 0 else 150000, seed=30 + tick)
+            sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+            assert np.array_equal(sa, sb)
+            live = np.concatenate([live, sa])
+            if tick:
+                cs = rng.choice(live, size=3000, replace=False)
+                a.cancel(cs)
+                b.cancel(cs)
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "group route tick %d" % tick, SCORE_TOL)
+            assert_same_state(a, b, cfg, "group route tick %d" % tick)
+            live = np.setdiff1d(live, ma.slots.ravel())
+
+
+@pytest.mark.parametrize("late,late0", [("1000", "512"), ("2", "100000000")])
+def test_gpu_team_late_kernel_forced(gpu_cls, oracle_cls, monkeypatch, late, late0):
+    """kt_late on the device far beyond its default reach: MM_TEAM_LATE=1000 hands every chain over after the first
+    two passes of every tick; MM_TEAM_LATE0=10^8 starts every tick in it (and the rich first passes of the big tick
+    make it hand the chains back: late_bail = 4 x 2 + 32 lobbies).  200k-player 5v5 pool, then arrivals + cancels."""
+    monkeypatch.setenv("MM_TEAM_LATE", late)
+    monkeypatch.setenv("MM_TEAM_LATE0", late0)
+    cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 19)
+    rng = np.random.default_rng(13)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        live = np.zeros(0, np.uint32)
+        for tick in range(4):
+            rating, cons = make_pool(200000 if tick == 0 else 3000, seed=40 + tick, role_weights=ROLE_WEIGHTS_5V5)
+            sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+            assert np.array_equal(sa, sb)
+            live = np.concatenate([live, sa])
+            if tick >= 2:
+                cs = rng.choice(live, size=200, replace=False)
+                a.cancel(cs)
+                b.cancel(cs)
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "kt_late forced tick %d" % tick, SCORE_TOL)
+            assert_same_state(a, b, cfg, "kt_late forced tick %d" % tick)
+            live = np.setdiff1d(live, ma.slots.ravel())
+
