@@ -140,6 +140,7 @@ def parse():
     ap.add_argument("--no-boundary", action="store_true",
                     help="skip the kernel-boundary micro-measurement (torch add kernels; tools/collect_profiles.sh "
                          "passes this so that the profiled command holds the engine's kernels only)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive leg (the pool handed over in host buffers)")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3 leg (BASELINE configs[2] beside the main line)")
     ap.add_argument("--cfg3-steps", type=int, default=12)
     ap.add_argument("--no-prediction", action="store_true",
@@ -608,6 +609,29 @@ def main():
                 line["cfg3"] = dict(secondary_pool_leg(w3, n, max(2, args.cfg3_steps),
                                                        os.path.join(ROOT, "profiles", "traffic_latest_5v5.json")),
                                     baseline_config="configs[2]" if n == 1_000_000 else "custom")
+            # the same step with the pool handed over in HOST buffers (mm_enqueue: H2D inside the clock) — the
+            # PCIe-inclusive rate; never `value`
+            if not args.no_pcie:
+                rating_h, cons_h = pool_of(wl, n)
+                pcfg = make_config(wl["modes"], capacity=pow2(n), device=local_rank, timing=False)
+                with Engine(pcfg) as peng:
+                    def pstep():
+                        peng.reset()
+                        peng.enqueue(rating_h, cons_h)
+                        return peng.tick(0, reuse=True)
+                    pstep()
+                    torch.cuda.synchronize()
+                    psteps = max(2, min(args.steps, 10))
+                    t0 = time.perf_counter()
+                    pm = 0
+                    for _ in range(psteps):
+                        pm += int(pstep().stats["players_matched"])
+                    torch.cuda.synchronize()
+                    pel = time.perf_counter() - t0
+                line["pcie_inclusive"] = {"value": pm / pel, "unit": "matched players/s", "ms_per_step": pel / psteps * 1e3,
+                                          "steps": psteps,
+                                          "note": "the pool in host memory: mm_enqueue copies rating + cons (8 B a player) to the "
+                                                  "device and the handles back inside the step; secondary, never `value`"}
             # cfg-4's pool on ONE GPU: the N=1 point of the strong-scaling curve of `--gpus N`
             n10 = args.shared_players
             if n10 and n10 != n:

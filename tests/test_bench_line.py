@@ -131,6 +131,7 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
     assert r["traffic"] is None and "traffic_note" in r   # the PMC figure belongs to the 1M-player workload only
     ex = d["exactness"]                              # the emission digest against the oracle's (committed) digest
     assert ex["ok"] is True and ex["emission_digest"] == ex["oracle_digest"] and ex["key"].startswith(mode + "/12000/")
+    assert d["pcie_inclusive"]["value"] > 0 and d["pcie_inclusive"]["steps"] == 2      # the pool handed over in host buffers
     sp = d["shared_pool_n1"]                         # cfg-4's pool on one GPU (here: 20000 players)
     assert sp["exact"] is True and sp["value"] > 0 and "20000 players" in sp["workload"]
     pr = sp["sharding_prediction"]                   # every rank's share of that pool, alone on this GPU
