@@ -1491,7 +1491,7 @@ static int ensure_staging(mm_engine* e, size_t n)
 // Shared by both enqueue entry points; all pointers are device pointers.
 static int enqueue_device_impl(mm_engine* e, uint32_t n, const int32_t* d_rating, const uint32_t* d_cons,
                                const uint8_t* d_group, const uint32_t* d_slot_sel, uint32_t* d_out_slot,
-                               uint32_t* rejected, float* bucket_ms)
+                               uint32_t* rejected, float* bucket_ms, uint32_t* h_out_slot = nullptr)
 {
     const uint32_t blocks = (n + BK_CHUNK - 1) / BK_CHUNK;
     const size_t rows = (size_t)blocks * BK_WAVES;
@@ -1516,6 +1516,8 @@ static int enqueue_device_impl(mm_engine* e, uint32_t n, const int32_t* d_rating
     HIPCHK(e, hipGetLastError());
     if (timing) HIPCHK(e, hipEventRecord(e->ev[1], e->stream));
     HIPCHK(e, hipMemcpyAsync(e->h_counters + 1, e->d_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    // the handles travel with the counter: one round trip to the device per enqueue, not two (a stream enqueues every tick)
+    if (h_out_slot) HIPCHK(e, hipMemcpyAsync(h_out_slot, d_out_slot, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     *rejected = e->h_counters[1];
     *bucket_ms = 0.f;
@@ -1585,13 +1587,12 @@ extern "C" int mm_enqueue(mm_engine* e, uint32_t n, const int32_t* rating, const
         if (group) HIPCHK(e, hipMemcpyAsync(e->d_in_group, group, n, hipMemcpyHostToDevice, e->stream));
         uint32_t rejected = 0;
         float bms = 0.f;
-        rc = enqueue_device_impl(e, n, e->d_in_rating, e->d_in_cons, group ? e->d_in_group : NULL,
-                                 contiguous ? NULL : e->d_in_sel, e->d_in_slot, &rejected, &bms);   // syncs: `sel` outlives the copy
-        if (rc) return rc;
         std::vector<uint32_t> tmp;
         uint32_t* slots = out_slot;
         if (!slots) { tmp.resize(n); slots = tmp.data(); }
-        HIPCHK(e, hipMemcpy(slots, e->d_in_slot, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        rc = enqueue_device_impl(e, n, e->d_in_rating, e->d_in_cons, group ? e->d_in_group : NULL,
+                                 contiguous ? NULL : e->d_in_sel, e->d_in_slot, &rejected, &bms, slots);   // syncs: `sel` outlives the copy
+        if (rc) return rc;
         for (uint32_t i = 0; i < n; ++i)
             if (slots[i] != MM_NO_SLOT) e->h_state[slots[i]] = MM_ST_LIVE;
         e->next_slot = contiguous ? (uint32_t)(((unsigned long long)e->next_slot + n) % e->cfg.capacity)
@@ -1733,25 +1734,31 @@ static int results_absorb(mm_engine* e, uint32_t L)
 
 // lobbies [r_sent[g], n_out[g]) of every group go out on the copy stream.  The emission lists only grow and every
 // kernel that wrote entries below n_out has finished (the caller has just synchronised the engine stream).
-static int results_send(mm_engine* e, const uint32_t* n_out, uint32_t L, uint32_t min_new)
+static int results_send(mm_engine* e, const uint32_t* n_out, uint32_t L, uint32_t min_new, bool* on_main = nullptr)
 {
     uint32_t fresh = 0;
     for (uint32_t g = 0; g < e->cfg.n_groups; ++g) fresh += n_out[g] > e->r_sent[g] ? n_out[g] - e->r_sent[g] : 0u;
+    if (on_main) *on_main = false;
     if (fresh < min_new) return MM_OK;
     int rc = results_absorb(e, L);                       // one batch of copies in flight at a time
     if (rc) return rc;
+    // the end of a tick with little left to send (every tick of a stream): on the engine's own stream, behind the
+    // walk — the caller synchronises that stream anyway, and a second stream's event would be one more round trip
+    const bool main_st = on_main != nullptr && fresh <= 8192u;
+    hipStream_t const st = main_st ? e->stream : e->copy_stream;
     for (uint32_t g = 0; g < e->cfg.n_groups; ++g) {
         const uint32_t a = e->r_sent[g], b = n_out[g];
         if (b <= a) continue;
         const size_t at = (size_t)e->r_base[g] + a;
         HIPCHK(e, hipMemcpyAsync(&e->h_rslots[at * L], e->d_out_slots + (size_t)g * e->out_slot_stride + (size_t)a * L,
-                                 (size_t)(b - a) * L * sizeof(uint32_t), hipMemcpyDeviceToHost, e->copy_stream));
+                                 (size_t)(b - a) * L * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipMemcpyAsync(&e->h_rscore[at], e->d_out_score + (size_t)g * e->out_rec_stride + a, (size_t)(b - a) * sizeof(float),
-                                 hipMemcpyDeviceToHost, e->copy_stream));
+                                 hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipMemcpyAsync(&e->h_rpass[at], e->d_out_pass + (size_t)g * e->out_rec_stride + a, (size_t)(b - a) * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, e->copy_stream));
+                                 hipMemcpyDeviceToHost, st));
         e->r_sent[g] = b;
     }
+    if (main_st) { *on_main = true; return MM_OK; }      // the caller marks the slots after its own synchronisation
     HIPCHK(e, hipEventRecord(e->ev_copy, e->copy_stream));
     e->ev_copy_pending = true;
     return MM_OK;
@@ -2300,6 +2307,7 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     if (e->fault_tick && ++e->ticks_seen == e->fault_tick) return MM_ERR_INTERNAL;   // test hook: a tick that dies after its walk
     if ((size_t)total * M.L > (size_t)cfg.capacity + (size_t)MM_MAX_LOBBY * G) return MM_ERR_INTERNAL;
     RoctxRange rr_res("mm_tick/match list");
+    bool tail_on_main = false;
     // The match list, group-major emission order.  Most of it left for the host while the walk was still running
     // (results_send at every look at the chains); what the last kernels emitted follows now, and the host does its
     // part for what has arrived meanwhile — ActiveUser.remove_user for the matched players (game-lobby/worker.ex:73-103).
@@ -2313,7 +2321,7 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                 return MM_ERR_INTERNAL;
         }
         if (!e->r_based) results_set_bases(e, bf, M.L);
-        int src = results_send(e, no, M.L, 1u);
+        int src = results_send(e, no, M.L, 1u, &tail_on_main);
         if (src) return src;
     }
     const uint32_t nrel = e->h_counters[0];
@@ -2331,6 +2339,8 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
         e->r_pre[g + 1u] = e->r_pre[g] + e->r_cnt[g];
     }
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (tail_on_main)
+        for (uint32_t g = 0; g < G; ++g) results_mark(e, g, e->r_sent[g], M.L);
     // ... and the slots the liveness filter released
     for (uint32_t i = 0; i < nrel; ++i) e->h_state[e->r_released[i]] = MM_ST_FREE;
     e->cancel_pending = e->cancel_pending >= nrel ? e->cancel_pending - nrel : 0;

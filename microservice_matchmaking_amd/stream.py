@@ -66,8 +66,14 @@ def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=
         rating, cons = stream_batch(n, sd, mode_weights, role_weights)
         arrival[first:first + n] = ts
         if realtime:
-            while time.perf_counter() - t_start < t_close:      # the period has to be over
-                pass
+            # the period has to be over: sleep through most of it and spin only for the last stretch (a thread that spins
+            # all the time is the first one a CPU quota throttles, for tens of milliseconds at a time)
+            while True:
+                left = t_close - (time.perf_counter() - t_start)
+                if left <= 0:
+                    break
+                if left > 0.0006:
+                    time.sleep(left - 0.0004)
         t0 = time.perf_counter()
         try:
             search.enqueue(rating, cons, first_global_index=first)
