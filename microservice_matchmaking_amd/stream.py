@@ -61,6 +61,12 @@ def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=
     matched = 0
     first = 0
     full_at_s = None
+    # (a generation-2 collection of the interpreter's heap is a pause of tens of milliseconds in one tick of a real-time
+    # run: nothing here makes reference cycles, so the collector rests until the stream is over)
+    import gc
+    gc_was = gc.isenabled()
+    if realtime:
+        gc.disable()
     t_start = time.perf_counter()
     for (t_open, t_close, n, sd, ts) in schedule:
         rating, cons = stream_batch(n, sd, mode_weights, role_weights)
@@ -101,6 +107,8 @@ def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=
                     emitted[(md, int(g))] += int(sel.shape[0])
         tick_cost.append(time.perf_counter() - t0)
     elapsed = time.perf_counter() - t_start
+    if realtime and gc_was:
+        gc.enable()
     depth = [search.engine.queue_depth(md).astype(np.int64) for md in range(n_modes)]
     cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0)
     return {
