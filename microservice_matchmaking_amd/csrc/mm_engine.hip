@@ -860,6 +860,30 @@ __global__ __launch_bounds__(WK_THREADS) void k_walk(WalkParams P)
     }
 }
 
+// The match list of a small tick (every tick of a stream) in ONE piece: the groups' emission logs gathered, emission
+// order, into a staging buffer laid out [slots: total x L | score: total | pass: total] — three copies to the host
+// instead of three per rating group (21 blit kernels and as many runtime calls for a tick that seats forty lobbies).
+struct PackArgs {
+    uint32_t pre[MM_MAX_GROUPS + 1];
+    uint32_t n_groups, L, total, out_slot_stride, out_rec_stride;
+};
+__global__ __launch_bounds__(256) void k_pack_results(PackArgs A, const uint32_t* __restrict__ out_slots,
+                                                      const float* __restrict__ out_score, const uint32_t* __restrict__ out_pass,
+                                                      uint32_t* __restrict__ pk)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.total) return;
+    uint32_t g = 0;
+    while (g + 1u < A.n_groups && i >= A.pre[g + 1u]) ++g;
+    const uint32_t j = i - A.pre[g];
+    const uint32_t* const src = out_slots + (size_t)g * A.out_slot_stride + (size_t)j * A.L;
+    uint32_t* const dst = pk + (size_t)i * A.L;
+    for (uint32_t k = 0; k < A.L; ++k) dst[k] = src[k];
+    pk[(size_t)A.total * A.L + i] = __float_as_uint(out_score[(size_t)g * A.out_rec_stride + j]);
+    pk[(size_t)A.total * (A.L + 1u) + i] = out_pass[(size_t)g * A.out_rec_stride + j];
+}
+#define MM_PACK_MAX 8192u            // lobbies of a tick up to which its match list is packed on the device
+
 #include "mm_pair.inc"
 #include "mm_team.inc"
 
@@ -919,6 +943,7 @@ struct mm_engine {
     bool pair_fused;           // MM_PAIR_FUSED=0: three launches per round instead of one (A/B testing)
     uint32_t round_ctr;
     uint32_t* d_pk_tilectl;
+    uint32_t* d_pack;          // the packed match list of a small tick (k_pack_results)
     uint4* d_pk_grec;          // second level of the route (kp_group)
     uint32_t pk_gstride;
     bool pair_xcd;             // MM_PAIR_XCD=0: kp_round on the plain (tile, group) grid (A/B)
@@ -1231,6 +1256,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); }
     (void)hipFree(e->d_pk_tilectl);
     (void)hipFree(e->d_pk_grec);
+    (void)hipFree(e->d_pack);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_tchains) (void)hipHostFree(e->h_tchains);
     if (e->h_rslots) (void)hipHostFree(e->h_rslots);
@@ -1361,6 +1387,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         CREATE_CHK(hipMalloc((void**)&e->d_chains, e->n_chains * sizeof(ChainDev)));
         CREATE_CHK(hipMalloc((void**)&e->d_state, cap));
         CREATE_CHK(hipMalloc((void**)&e->d_released, (cap + 64) * sizeof(uint32_t)));
+        CREATE_CHK(hipMalloc((void**)&e->d_pack, (size_t)MM_PACK_MAX * (MM_MAX_LOBBY + 2u) * sizeof(uint32_t)));
         CREATE_CHK(hipMalloc((void**)&e->d_counters, 2 * sizeof(uint32_t)));
         // emission logs: a group can emit at most (cap + lobby) / 2 lobbies of >= 2 players
         e->out_slot_stride = (uint32_t)(cap + 64);
@@ -1868,7 +1895,13 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     const uint32_t bound = (uint32_t)bound64;
     hipLaunchKernelGGL(kp_init, dim3(G), dim3(1024), 0, e->stream, P, cfg.capacity);
     hipLaunchKernelGGL(kp_pack, dim3((bound + 32u + 1023u) / 1024u, G), dim3(1024), 0, e->stream, P);
-    hipLaunchKernelGGL(kp_nx_init, dim3((bound + NXI_SEG - 1u) / NXI_SEG + 1u, G), dim3(NXI_THREADS), 0, e->stream, P);
+    {
+        // a workgroup walks its anchors eight at a time (one wave each): 2048 anchors per workgroup keep a big pool's staging
+        // traffic low, but a stream's tick has a few hundred players per chain, all in ONE workgroup then (147 us per tick
+        // measured) — 256 anchors per workgroup while the pool is small
+        const uint32_t seg = bound <= 65536u ? 256u : NXI_SEG;
+        hipLaunchKernelGGL(kp_nx_init, dim3((bound + seg - 1u) / seg + 1u, G), dim3(NXI_THREADS), 0, e->stream, P, seg);
+    }
     HIPCHK(e, hipGetLastError());
     // ---- tiled rounds for the chains that do not fit one workgroup's LDS ----
     if (bound >= PL_MAX) {
@@ -2320,9 +2353,25 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
             if (e->r_based && (c.n_out < e->r_sent[g] || (unsigned long long)c.n_out * M.L > (unsigned long long)c.before + M.L))
                 return MM_ERR_INTERNAL;
         }
-        if (!e->r_based) results_set_bases(e, bf, M.L);
-        int src = results_send(e, no, M.L, 1u, &tail_on_main);
-        if (src) return src;
+        if (!e->r_based && total > 0u && total <= MM_PACK_MAX) {
+            // nothing has left yet and the tick is small: one packed piece, tight layout (group g at its prefix)
+            PackArgs A;
+            memset(&A, 0, sizeof(A));
+            A.n_groups = G; A.L = M.L; A.total = total; A.out_slot_stride = e->out_slot_stride; A.out_rec_stride = e->out_rec_stride;
+            for (uint32_t g = 0; g < G; ++g) { A.pre[g + 1u] = A.pre[g] + no[g]; e->r_base[g] = A.pre[g]; e->r_sent[g] = no[g]; }
+            e->r_based = true;
+            hipLaunchKernelGGL(k_pack_results, dim3((total + 255u) / 256u), dim3(256), 0, e->stream, A, e->d_out_slots, e->d_out_score,
+                               e->d_out_pass, e->d_pack);
+            HIPCHK(e, hipGetLastError());
+            HIPCHK(e, hipMemcpyAsync(e->h_rslots, e->d_pack, (size_t)total * M.L * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->h_rscore, e->d_pack + (size_t)total * M.L, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->h_rpass, e->d_pack + (size_t)total * (M.L + 1u), (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+            tail_on_main = true;
+        } else {
+            if (!e->r_based) results_set_bases(e, bf, M.L);
+            int src = results_send(e, no, M.L, 1u, &tail_on_main);
+            if (src) return src;
+        }
     }
     const uint32_t nrel = e->h_counters[0];
     e->r_released.resize(nrel);

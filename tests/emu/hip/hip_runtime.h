@@ -87,6 +87,7 @@ static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long l
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, sizeof(u)); return u; }
 
 /* wave_sync() of the engine: a fence is a no-op here, the wave barrier is a rendezvous */
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
