@@ -64,6 +64,7 @@
 #define MM_ERRF_OUT_OVERFLOW 2u
 #define MM_ERRF_SEAT_INVARIANT 4u
 #define MM_ERRF_PASS_LIMIT 8u
+#define MM_ERRF_SYNC_TIMEOUT 16u      // an emitter workgroup of kt_chase gave up waiting for its chaser
 
 struct LobbyDev {                                 // the record LobbyState stores
     uint32_t n;
@@ -513,7 +514,7 @@ struct LobbySum {
     uint32_t free, full;                                  // 4 bits per role, seats over all teams
 };
 
-static __device__ void lsum_load(LobbySum& L, const LobbyDev& lb, const ModeDev& M)
+static __device__ __forceinline__ void lsum_load(LobbySum& L, const LobbyDev& lb, const ModeDev& M)
 {
     L.n = lb.n;
     L.full = 0;
@@ -542,7 +543,7 @@ static __device__ void lsum_load(LobbySum& L, const LobbyDev& lb, const ModeDev&
 // docs/MATCH_CHECK.md §2.3-2.4 for a player already known to pass §2.2 (or an empty lobby):
 // the eligible team with the smallest rating sum, lowest index on a tie; -1 if no team has a
 // free seat of the role.
-static __device__ int lsum_seat(LobbySum& L, LobbyDev& lb, const ModeDev& M, int32_t r, uint32_t cn, uint32_t slot, int lane)
+static __device__ __forceinline__ int lsum_seat(LobbySum& L, LobbyDev& lb, const ModeDev& M, int32_t r, uint32_t cn, uint32_t slot, int lane)
 {
     const uint32_t role = (cn >> 16) & 7u;
     int best = -1;
@@ -966,6 +967,9 @@ struct mm_engine {
     uint16_t* d_tk_memb;       // [group][pk_stride][tk_memb] ... and all of them (team modes only)
     uint32_t* d_tk_bitsB;      // [group][pk_bits_stride] the queue bitmap when kt_build last ran
     uint32_t* d_tk_chunkB;     // [group][role][tk_chunk_stride] chunk populations when kt_build last ran
+    uint32_t* d_tk_fdone;      // [group][tk_chunk_stride] kt_fc: the launch (team_seq) whose kt_f chunk has stored its F
+    uint32_t team_seq;         // kt_chase / kt_fc launches of this engine so far (never 0: it names a launch to its workgroups)
+    bool team_live;            // MM_TEAM_LIVE: kt_f and the chase of a pass in one launch (kt_fc) where there is no kt_f2
     uint32_t* d_tk_sqi;        // [group][pk_stride] position -> sub-queue entry
     uint32_t team_rebuild;     // MM_TEAM_REBUILD: kt_build runs in the first two passes of a tick and every this many after
     uint32_t tk_memb;          // largest lobby of a team mode, less the anchor
@@ -974,6 +978,7 @@ struct mm_engine {
     uint32_t team_batch;       // MM_TEAM_BATCH: passes launched per host look at the chains
     uint32_t team_cap;         // MM_TEAM_CAP: TeamParams.scan_cap
     uint32_t team_late;        // MM_TEAM_LATE: lobbies per pass at or under which kt_late takes the chains over (0 = never)
+    bool team_fused;           // MM_TEAM_FUSED: the emitter workgroups ride in kt_chase's launch (mm_team.inc)
     uint32_t team_late0;       // MM_TEAM_LATE0: arrivals of a mode since its last tick at or under which kt_late walks the tick from its first pass
     std::vector<uint32_t> tk_last_len;   // [chain] queue + stored lobby after the chain's last tick (what a quiescent tick left)
     uint32_t dbg_last_w, dbg_last_c;   // MM_PAIR_DEBUG + MM_TEAM_BATCH=1: per-pass deltas of the F counters
@@ -1244,6 +1249,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_tk_memb);
     (void)hipFree(e->d_tk_bitsB);
     (void)hipFree(e->d_tk_chunkB);
+    (void)hipFree(e->d_tk_fdone);
     (void)hipFree(e->d_tk_sqi);
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(e->d_pk_key[b]); (void)hipFree(e->d_pk_oidx[b]);
@@ -1342,6 +1348,11 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* trb = getenv("MM_TEAM_REBUILD");
             e->team_rebuild = trb ? (uint32_t)strtoul(trb, NULL, 0) : 8u;   // 4 / 6 / 8 measured within 0.1 ms of each other, 16: +0.9 ms, every pass: +1.4 ms
             if (e->team_rebuild < 1u) e->team_rebuild = 1u;
+            const char* tfe = getenv("MM_TEAM_FUSED");
+            e->team_fused = !(tfe && tfe[0] == '0');                     // 0: kt_emit as a launch of its own behind every chase (cfg-3: +1.3 ms per tick)
+            const char* tlv = getenv("MM_TEAM_LIVE");
+            e->team_live = !(tlv && tlv[0] == '0');                      // 0: kt_f and kt_chase as launches of their own in every pass (cfg-3: +0.7 ms per tick)
+            e->team_seq = 0;
             const char* tl0 = getenv("MM_TEAM_LATE0");
             e->team_late0 = tl0 ? (uint32_t)strtoul(tl0, NULL, 0) : 512u;
             e->tk_last_len.assign(e->n_chains, 0u);
@@ -1444,6 +1455,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
                 CREATE_CHK(hipMalloc((void**)&e->d_tk_bitsB, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
                 CREATE_CHK(hipMalloc((void**)&e->d_tk_chunkB, (size_t)cfg->n_groups * MM_MAX_ROLES * e->tk_chunk_stride * sizeof(uint32_t)));
                 CREATE_CHK(hipMalloc((void**)&e->d_tk_sqi, gc * sizeof(uint32_t)));
+                CREATE_CHK(hipMalloc((void**)&e->d_tk_fdone, (size_t)cfg->n_groups * e->tk_chunk_stride * sizeof(uint32_t)));
+                CREATE_CHK(hipMemsetAsync(e->d_tk_fdone, 0, (size_t)cfg->n_groups * e->tk_chunk_stride * sizeof(uint32_t), e->stream));
             }
             CREATE_CHK(hipHostMalloc((void**)&e->h_tchains, cfg->n_groups * sizeof(TeamChain), hipHostMallocDefault));
             CREATE_CHK(hipMemsetAsync(e->d_tchains, 0, cfg->n_groups * sizeof(TeamChain), e->stream));
@@ -1460,6 +1473,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             W.tchains = e->d_tchains;
             W.chains = e->d_chains;
             hipLaunchKernelGGL(kt_late, dim3(cfg->n_groups), dim3(TL_THREADS), 0, e->stream, W);
+            hipLaunchKernelGGL(kt_fc, dim3(cfg->n_groups), dim3(TT_CH), 0, e->stream, W);
             CREATE_CHK(hipGetLastError());
         }
     #undef CREATE_CHK
@@ -2033,6 +2047,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     P.scan_cap = e->team_cap;
     P.late_bail = 4u * e->team_late + 32u;
     P.debug = e->pair_debug ? 1u : 0u;
+    P.seq = 0;
+    P.n_emit = 0;
     P.M = M;
     P.chains = e->d_chains;
     P.tchains = e->d_tchains;
@@ -2054,6 +2070,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     P.bitsB = e->d_tk_bitsB;
     P.chunkB = e->d_tk_chunkB;
     P.sqi = e->d_tk_sqi;
+    P.fdone = e->d_tk_fdone;
     P.use_f2 = 0;
     P.out_slots = e->d_out_slots;
     P.out_score = e->d_out_score;
@@ -2087,6 +2104,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     // after a pass that seated many lobbies after all (`late_bail`); the sub-queues are rebuilt then (it leaves no
     // tombstones behind).
     uint32_t pass = 0, batch = e->team_batch < 2u ? e->team_batch : 2u;
+    uint32_t n_emit = longest / (M.L * TC_WAVES * 8u) + 1u;          // the first passes: one wave per lobby if an eighth of the chain is seated
+    if (n_emit > TC_EMIT_MAX) n_emit = TC_EMIT_MAX;
     uint32_t team_no[MM_MAX_GROUPS];
     bool team_have = false, force_build = false;
     bool late_now = late_ok && e->team_late0 != 0u && arrivals <= e->team_late0;
@@ -2106,11 +2125,23 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
                 if (pass < 2u || pass % e->team_rebuild == 0u || force_build)
                     hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
                 force_build = false;
-                hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
-                if (P.use_f2) hipLaunchKernelGGL(kt_f2, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
-                if (P.use_f2) hipLaunchKernelGGL(kt_chase<1>, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
-                else hipLaunchKernelGGL(kt_chase<0>, dim3(G), dim3(TC_THREADS), 0, e->stream, P);
-                hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
+                // the emitters ride in the chase's launch, enough waves for the lobbies the last look saw per pass (a pass
+                // that emits more than that is only slower); MM_TEAM_FUSED=0: kt_emit as a launch of its own behind it
+                if (++e->team_seq == 0u) e->team_seq = 1u;
+                P.seq = e->team_seq;
+                P.n_emit = e->team_fused ? n_emit : 0u;
+                if (P.use_f2) {
+                    hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+                    hipLaunchKernelGGL(kt_f2, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+                    hipLaunchKernelGGL(kt_chase<1>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
+                } else if (e->team_live) {
+                    // kt_f and the chase of the pass in one launch: the chasers take F chunk by chunk as it is written
+                    hipLaunchKernelGGL(kt_fc, dim3(G * (1u + P.n_emit) + G * nch), dim3(TT_CH), 0, e->stream, P);
+                } else {
+                    hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+                    hipLaunchKernelGGL(kt_chase<0>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
+                }
+                if (!e->team_fused) hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
             }
         }
         HIPCHK(e, hipGetLastError());
@@ -2168,6 +2199,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             continue;
         }
         late_now = late;
+        n_emit = most / TC_WAVES + 1u;
+        if (n_emit > TC_EMIT_MAX) n_emit = TC_EMIT_MAX;
         // close to the switch: look again soon (a look costs a D2H round trip, an idle pass three launches)
         batch = (e->team_late && most <= 3u * e->team_late) ? (e->team_batch < 4u ? e->team_batch : 4u) : e->team_batch;
     }
@@ -2181,9 +2214,11 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             const uint32_t np = t.passes + 1u;
             fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | "
                     "kt_f, the middle chunk, cycles per pass: set-up %u, windows + step A %u, scans %u, long scans %u, lobbies %u, step C %u; anchors looked up per pass %u | "
-                    "F values written %u, changed after the first pass %u\n", g, t.fast, t.m, t.passes, t.n_out, t.qlen,
+                    "F values written %u, changed after the first pass %u | kt_chase: 64-entry steps of the stored lobby's fills %u, of %u look-ups %u\n",
+                    g, t.fast, t.m, t.passes, t.n_out, t.qlen,
                     t.dbg[6] & 1u, (t.dbg[6] >> 1) & 1u, (t.dbg[6] >> 2) & 1u, t.dbg[7],
-                    t.tmk[0] / np, t.tmk[1] / np, t.tmk[2] / np, t.tmk[3] / np, t.tmk[4] / np, t.tmk[5] / np, t.dbg[2] / np, t.dbg[5], t.dbg[4]);
+                    t.tmk[0] / np, t.tmk[1] / np, t.tmk[2] / np, t.tmk[3] / np, t.tmk[4] / np, t.tmk[5] / np, t.dbg[2] / np, t.dbg[5], t.dbg[4],
+                    t.dbg[0], t.dbg[3], t.dbg[1]);
         }
     return MM_OK;
 }

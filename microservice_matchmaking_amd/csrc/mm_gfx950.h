@@ -52,6 +52,19 @@ static __device__ __forceinline__ void tw_sload4_v(const uint32_t* p, uint32_t& 
     v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
 }
 
+// every store this wave has issued has been acknowledged (gfx9: vmcnt counts stores too).  After write-through
+// (agent-scope atomic) stores: they are in memory, and a flag stored next is seen after them
+static __device__ __forceinline__ void tw_store_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// kt_fc: workgroups that WAIT for others of their launch (the chasers, the emitters) have the lowest indices — the
+// hardware dispatches in index order, so whoever they wait for is behind them in the queue but never blocked by them
+// (they hold 7 + a few of the chip's workgroup slots).  The CPU shim of the tests runs workgroups one after another and
+// needs the opposite order (tests/emu/mm_gfx950.h).
+#define MM_WAITERS_FIRST 1
+
+// register budget of a kernel: exactly n waves per SIMD (512 / n vector registers a lane)
+#define MM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
 // which of the eight XCDs this wave runs on (diagnostics: workgroup -> XCD placement is observed, not promised)
 static __device__ __forceinline__ uint32_t mm_xcc_id()
 {

@@ -99,6 +99,7 @@ static inline long long clock64(void) { return 0; }
 static inline long long wall_clock64(void) { return 0; }
 /* relaxed workgroup-scope atomics: plain accesses through a volatile lvalue */
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
 #define __hip_atomic_load(p, order, scope) (*(const volatile __typeof__(*(p))*)(p))
 #define __hip_atomic_store(p, v, order, scope) ((void)(*(volatile __typeof__(*(p))*)(p) = (v)))
 #define __builtin_amdgcn_readlane(v, l) emu_shfl_i32((v), (l))

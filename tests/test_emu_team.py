@@ -213,3 +213,28 @@ def test_kt_late_hands_a_chain_back_after_a_rich_pass(oracle_cls, monkeypatch):
     monkeypatch.setenv("MM_TEAM_LATE0", "10000000")
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 12000, seed=9, n_ticks=2,
                  weights=[0.2] * 5, capacity=1 << 15) > 300
+
+
+@pytest.mark.parametrize("f2,live,fused", [("0", "1", "0"), ("0", "1", "1"), ("2", "1", "1"), ("1000", "0", "1"),
+                                           ("0", "0", "0")])
+def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused):
+    """A pass is kt_f + kt_chase + kt_emit as three launches, or kt_f and the chase in one (kt_fc: MM_TEAM_LIVE, the
+    passes from MM_TEAM_F2 on), or with the emitter workgroups riding in the chase's launch (MM_TEAM_FUSED) — every
+    combination must give the oracle's ticks: cancel ticks, stored lobbies, the scan cap, the starving stream.  (Under
+    the shim the workgroups of a launch run one after another, the ones that wait last: this tests the roles' logic and
+    the publish / take protocol, not their overlap — test_gpu_parity.py does that.)"""
+    from helpers import run_starving_team_stream
+    monkeypatch.setenv("MM_TEAM_F2", f2)
+    monkeypatch.setenv("MM_TEAM_LIVE", live)
+    monkeypatch.setenv("MM_TEAM_FUSED", fused)
+    monkeypatch.setenv("MM_TEAM_LATE", "0")
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=13, weights=W5) > 50
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=14, regions=2) > 50
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=15, lo=0, hi=900) > 20   # narrow window: the scan cap
+    per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
+                                          capacity=1 << 14)
+    assert sum(per) > 0
+    cfg = make_config([mode_team(3, 2, 400, (2, 1), region_filter=True)], capacity=1 << 13)
+    rng = np.random.default_rng(16)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        random_scenario(rng, cfg, a, b, n_rounds=4, batch=1500, cancel_frac=0.05)

@@ -386,6 +386,41 @@ def test_gpu_pair_second_route_level_forced(gpu_cls, oracle_cls, monkeypatch):
             live = np.setdiff1d(live, ma.slots.ravel())
 
 
+@pytest.mark.parametrize("f2,live,fused", [("0", "1", "0"), ("0", "1", "1"), ("1000", "0", "1"), ("32", "0", "0")])
+def test_gpu_team_every_launch_shape_of_a_pass(gpu_cls, oracle_cls, monkeypatch, f2, live, fused):
+    """The three ways a pass of the team path is launched — kt_f / kt_chase / kt_emit one behind the other; kt_f and
+    the chase in one launch (kt_fc, the chasers taking F chunk by chunk while kt_f is still at work: MM_TEAM_LIVE, from
+    pass MM_TEAM_F2 on); the emitter workgroups in the chase's launch (MM_TEAM_FUSED) — on the device, where the
+    workgroups of a launch really overlap: 200k-player 5v5 pool, then arrivals + cancels, and a dense 3 x 2 mode."""
+    monkeypatch.setenv("MM_TEAM_F2", f2)
+    monkeypatch.setenv("MM_TEAM_LIVE", live)
+    monkeypatch.setenv("MM_TEAM_FUSED", fused)
+    cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 19)
+    rng = np.random.default_rng(17)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        live_slots = np.zeros(0, np.uint32)
+        for tick in range(4):
+            rating, cons = make_pool(200000 if tick == 0 else 3000, seed=50 + tick, role_weights=ROLE_WEIGHTS_5V5)
+            sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+            assert np.array_equal(sa, sb)
+            live_slots = np.concatenate([live_slots, sa])
+            if tick >= 2:
+                cs = rng.choice(live_slots, size=200, replace=False)
+                a.cancel(cs)
+                b.cancel(cs)
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "launch shape tick %d" % tick, SCORE_TOL)
+            assert_same_state(a, b, cfg, "launch shape tick %d" % tick)
+            live_slots = np.setdiff1d(live_slots, ma.slots.ravel())
+    cfg = make_config([mode_team(2, 3, 400, (1, 1), region_filter=True)], capacity=1 << 18)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        for tick in range(2):
+            rating, cons = make_pool(120000 if tick == 0 else 20000, seed=60 + tick, n_regions=3, role_weights=(3, 2))
+            assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+            assert_same_tick(a.tick(0), b.tick(0), "launch shape 3x2 tick %d" % tick, SCORE_TOL)
+            assert_same_state(a, b, cfg, "launch shape 3x2 tick %d" % tick)
+
+
 @pytest.mark.parametrize("late,late0", [("1000", "512"), ("2", "100000000")])
 def test_gpu_team_late_kernel_forced(gpu_cls, oracle_cls, monkeypatch, late, late0):
     """kt_late on the device far beyond its default reach: MM_TEAM_LATE=1000 hands every chain over after the first
