@@ -2046,7 +2046,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     P.n_released = e->d_counters;
     P.scan_cap = e->team_cap;
     P.late_bail = 4u * e->team_late + 32u;
-    P.debug = e->pair_debug ? 1u : 0u;
+    P.debug = e->pair_debug ? (e->team_batch == 1u ? 3u : 1u) : 0u;   // bit 1 (with MM_TEAM_BATCH=1): kt_f counts every F it writes — an atomic per thread
     P.seq = 0;
     P.n_emit = 0;
     P.M = M;
@@ -2093,6 +2093,29 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     if (!longest) return MM_OK;
     *any = true;
     const uint32_t nch = (longest + TT_CH - 1u) / TT_CH;
+    uint32_t fo_total = 0;
+    {   // kt_fc's order of kt_f's workgroups (TeamParams.fo_*): the chains by falling length, aligned at their ends
+        uint32_t ord[MM_MAX_GROUPS], len[MM_MAX_GROUPS], K = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            const TeamChain& t = e->h_tchains[g];
+            if (!t.fast || t.m == 0u) continue;
+            const uint32_t n = (t.m + TT_CH - 1u) / TT_CH;
+            uint32_t at = K++;
+            while (at > 0u && len[at - 1u] < n) { ord[at] = ord[at - 1u]; len[at] = len[at - 1u]; --at; }
+            ord[at] = g;
+            len[at] = n;
+        }
+        P.fo_n = K;
+        for (uint32_t s = 0; s < K; ++s) {
+            P.fo_chain[s] = ord[s];
+            P.fo_nch[s] = len[s];
+            P.fo_start[s] = fo_total;
+            P.fo_dhi[s] = len[s];
+            fo_total += (s + 1u) * (len[s] - (s + 1u < K ? len[s + 1u] : 0u));
+        }
+        P.fo_start[K] = fo_total;
+        P.fo_dhi[K] = 0;
+    }
     uint32_t ex = longest / (M.L * TE_WAVES * 2u) + 1u;
     if (ex > 256u) ex = 256u;
     hipLaunchKernelGGL(kt_pack, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
@@ -2104,7 +2127,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     // after a pass that seated many lobbies after all (`late_bail`); the sub-queues are rebuilt then (it leaves no
     // tombstones behind).
     uint32_t pass = 0, batch = e->team_batch < 2u ? e->team_batch : 2u;
-    uint32_t n_emit = longest / (M.L * TC_WAVES * 8u) + 1u;          // the first passes: one wave per lobby if an eighth of the chain is seated
+    uint32_t n_emit = longest / (M.L * TC_WAVES * 8u) + 1u;          // the first passes: a worker wave per lobby if an eighth of the chain is seated
     if (n_emit > TC_EMIT_MAX) n_emit = TC_EMIT_MAX;
     uint32_t team_no[MM_MAX_GROUPS];
     bool team_have = false, force_build = false;
@@ -2136,7 +2159,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
                     hipLaunchKernelGGL(kt_chase<1>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
                 } else if (e->team_live) {
                     // kt_f and the chase of the pass in one launch: the chasers take F chunk by chunk as it is written
-                    hipLaunchKernelGGL(kt_fc, dim3(G * (1u + P.n_emit) + G * nch), dim3(TT_CH), 0, e->stream, P);
+                    hipLaunchKernelGGL(kt_fc, dim3(G * (1u + P.n_emit) + fo_total), dim3(TT_CH), 0, e->stream, P);
                 } else {
                     hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
                     hipLaunchKernelGGL(kt_chase<0>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
@@ -2199,7 +2222,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             continue;
         }
         late_now = late;
-        n_emit = most / TC_WAVES + 1u;
+        n_emit = most / (TT_WAVES - 1u) + 1u;                         // (kt_fc's emitter workgroups have seven worker waves)
         if (n_emit > TC_EMIT_MAX) n_emit = TC_EMIT_MAX;
         // close to the switch: look again soon (a look costs a D2H round trip, an idle pass three launches)
         batch = (e->team_late && most <= 3u * e->team_late) ? (e->team_batch < 4u ? e->team_batch : 4u) : e->team_batch;
@@ -2214,11 +2237,16 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             const uint32_t np = t.passes + 1u;
             fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | "
                     "kt_f, the middle chunk, cycles per pass: set-up %u, windows + step A %u, scans %u, long scans %u, lobbies %u, step C %u; anchors looked up per pass %u | "
-                    "F values written %u, changed after the first pass %u | kt_chase: 64-entry steps of the stored lobby's fills %u, of %u look-ups %u\n",
+                    "F values written %u, changed after the first pass %u | kt_chase: sub-queue entries looked at by the stored lobby's fills %u, by %u look-ups %u\n",
                     g, t.fast, t.m, t.passes, t.n_out, t.qlen,
                     t.dbg[6] & 1u, (t.dbg[6] >> 1) & 1u, (t.dbg[6] >> 2) & 1u, t.dbg[7],
                     t.tmk[0] / np, t.tmk[1] / np, t.tmk[2] / np, t.tmk[3] / np, t.tmk[4] / np, t.tmk[5] / np, t.dbg[2] / np, t.dbg[5], t.dbg[4],
                     t.dbg[0], t.dbg[3], t.dbg[1]);
+            if (t.lt[11])
+                fprintf(stderr, "[mm-team] g%u kt_fc's chaser: %u passes, %u lobbies by F; cycles per pass: all %u, the chase loop %u, its hops by F %u, of them on kt_f's flags %u; "
+                        "cycles per hop without the flags %u\n",
+                        g, t.lt[11], t.lt[12], 16u * (t.lt[9] / t.lt[11]), 16u * (t.lt[10] / t.lt[11]), 16u * (t.lt[13] / t.lt[11]), 16u * (t.lt[8] / t.lt[11]),
+                        t.lt[12] ? (uint32_t)(16ull * (t.lt[13] - t.lt[8]) / t.lt[12]) : 0u);
         }
     return MM_OK;
 }

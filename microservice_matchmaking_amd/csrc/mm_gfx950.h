@@ -62,8 +62,9 @@ static __device__ __forceinline__ void tw_store_wait() { asm volatile("s_waitcnt
 // needs the opposite order (tests/emu/mm_gfx950.h).
 #define MM_WAITERS_FIRST 1
 
-// register budget of a kernel: exactly n waves per SIMD (512 / n vector registers a lane)
-#define MM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+// a kernel's register budget as waves per SIMD (kt_fc: six = 80 vector registers = three 512-thread workgroups a CU;
+// measured: at two workgroups a CU a cfg-3 tick costs 0.5 ms more, at four nothing less)
+#define MM_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
 // which of the eight XCDs this wave runs on (diagnostics: workgroup -> XCD placement is observed, not promised)
 static __device__ __forceinline__ uint32_t mm_xcc_id()

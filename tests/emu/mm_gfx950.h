@@ -12,5 +12,5 @@ static inline uint32_t mm_xcc_id() { return 0; }
 static inline void tw_store_wait() {}
 // workgroups run one after another here: the ones that wait for others of their launch come last
 #define MM_WAITERS_FIRST 0
-#define MM_WAVES_PER_EU(n)
+#define MM_WAVES_PER_SIMD(n)
 #endif
