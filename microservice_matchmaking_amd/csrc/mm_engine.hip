@@ -31,7 +31,7 @@
 //           for short chains (kp_late).  DESIGN.md §4.3.
 //   mm_team.inc   the team-mode walk: per pass, role sub-queues and F[a] = the player the
 //           cursor picks after a's lobby, for every queued a at once, then a pointer chase
-//           (kt_build / kt_f / kt_chase / kt_emit).  DESIGN.md §4.4.
+//           (kt_build / kt_f / kt_f2 / kt_chase / kt_fc / kt_late).  DESIGN.md §4.4.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
@@ -969,6 +969,7 @@ struct mm_engine {
     uint32_t* d_tk_chunkB;     // [group][role][tk_chunk_stride] chunk populations when kt_build last ran
     uint32_t* d_tk_fdone;      // [group][tk_chunk_stride] kt_fc: the launch (team_seq) whose kt_f chunk has stored its F
     uint32_t team_seq;         // kt_chase / kt_fc launches of this engine so far (never 0: it names a launch to its workgroups)
+    uint32_t team_emit_max;    // MM_TEAM_EMIT_MAX
     bool team_live;            // MM_TEAM_LIVE: kt_f and the chase of a pass in one launch (kt_fc) where there is no kt_f2
     uint32_t* d_tk_sqi;        // [group][pk_stride] position -> sub-queue entry
     uint32_t team_rebuild;     // MM_TEAM_REBUILD: kt_build runs in the first two passes of a tick and every this many after
@@ -1350,6 +1351,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             if (e->team_rebuild < 1u) e->team_rebuild = 1u;
             const char* tfe = getenv("MM_TEAM_FUSED");
             e->team_fused = !(tfe && tfe[0] == '0');                     // 0: kt_emit as a launch of its own behind every chase (cfg-3: +1.3 ms per tick)
+            const char* tem = getenv("MM_TEAM_EMIT_MAX");
+            e->team_emit_max = tem ? (uint32_t)strtoul(tem, NULL, 0) : TC_EMIT_MAX;   // emitter workgroups per chain and launch at most
+            if (e->team_emit_max < 1u) e->team_emit_max = 1u;
             const char* tlv = getenv("MM_TEAM_LIVE");
             e->team_live = !(tlv && tlv[0] == '0');                      // 0: kt_f and kt_chase as launches of their own in every pass (cfg-3: +0.7 ms per tick)
             e->team_seq = 0;
@@ -1359,9 +1363,9 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* rse = getenv("MM_RESULTS_EARLY");
             e->results_early = !(rse && rse[0] == '0');
             const char* tlt = getenv("MM_TEAM_LATE");
-            // measured on cfg-3 (profiles/r03_ab_team_late.txt): 0: 12.99 ms, 3: 12.50, 6: 12.46, 12: 12.76, 20: 13.67, 40: 15.73 per tick —
-            // a look-up costs the chaser ~5 us (dependent trips to memory at ~1.5 us each when seven workgroups are all
-            // that runs), so it only beats the three launches of a pass while a pass seats a handful of lobbies
+            // measured on cfg-3 (profiles/r03_ab_team_late.txt): 0: 12.99 ms, 3: 12.50, 6: 12.46, 12: 12.76, 20: 13.67, 40: 15.73 per tick,
+            // and again with one launch per pass (kt_fc): 0: 10.9, 6: 9.89, 12: 10.01, 20: 10.6 — a look-up costs the chaser ~4 us
+            // (dependent trips to memory at ~1.2 us each), so it only beats a pass kernel while a pass seats a handful of lobbies
             e->team_late = tlt ? (uint32_t)strtoul(tlt, NULL, 0) : 6u;
             const char* tcap = getenv("MM_TEAM_CAP");
             e->team_cap = tcap ? (uint32_t)strtoul(tcap, NULL, 0) : TT_SCAN_CAP;
@@ -2128,7 +2132,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     // tombstones behind).
     uint32_t pass = 0, batch = e->team_batch < 2u ? e->team_batch : 2u;
     uint32_t n_emit = longest / (M.L * TC_WAVES * 8u) + 1u;          // the first passes: a worker wave per lobby if an eighth of the chain is seated
-    if (n_emit > TC_EMIT_MAX) n_emit = TC_EMIT_MAX;
+    if (n_emit > e->team_emit_max) n_emit = e->team_emit_max;
     uint32_t team_no[MM_MAX_GROUPS];
     bool team_have = false, force_build = false;
     bool late_now = late_ok && e->team_late0 != 0u && arrivals <= e->team_late0;
@@ -2223,8 +2227,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         }
         late_now = late;
         n_emit = most / (TT_WAVES - 1u) + 1u;                         // (kt_fc's emitter workgroups have seven worker waves)
-        if (n_emit > TC_EMIT_MAX) n_emit = TC_EMIT_MAX;
-        // close to the switch: look again soon (a look costs a D2H round trip, an idle pass three launches)
+        if (n_emit > e->team_emit_max) n_emit = e->team_emit_max;
+        // close to the switch: look again soon (a look costs a D2H round trip, an idle pass a launch)
         batch = (e->team_late && most <= 3u * e->team_late) ? (e->team_batch < 4u ? e->team_batch : 4u) : e->team_batch;
     }
     hipLaunchKernelGGL(kt_fin_scatter, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);

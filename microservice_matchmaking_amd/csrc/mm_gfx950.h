@@ -56,10 +56,11 @@ static __device__ __forceinline__ void tw_sload4_v(const uint32_t* p, uint32_t& 
 // (agent-scope atomic) stores: they are in memory, and a flag stored next is seen after them
 static __device__ __forceinline__ void tw_store_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// kt_fc: workgroups that WAIT for others of their launch (the chasers, the emitters) have the lowest indices — the
-// hardware dispatches in index order, so whoever they wait for is behind them in the queue but never blocked by them
-// (they hold 7 + a few of the chip's workgroup slots).  The CPU shim of the tests runs workgroups one after another and
-// needs the opposite order (tests/emu/mm_gfx950.h).
+// Workgroups that WAIT for others of their launch (kt_chase's emitters for its chasers; kt_fc's chasers for kt_f's
+// chunks, its emitters for the chasers) come in an order that lets the hardware's in-order dispatch work for them: whoever
+// is waited for is on the chip, or can get there, before the one that waits can fill it (mm_team.inc, kt_fc).  The CPU
+// shim of the tests runs workgroups one after another and needs the ones that are waited for FIRST
+// (tests/emu/mm_gfx950.h).
 #define MM_WAITERS_FIRST 1
 
 // a kernel's register budget as waves per SIMD (kt_fc: six = 80 vector registers = three 512-thread workgroups a CU;
