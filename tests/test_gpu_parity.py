@@ -148,6 +148,18 @@ def test_gpu_team_path_on_a_starving_stream(gpu_cls, oracle_cls):
     assert 0 < np.median(per) <= 40 and min(per[5:]) <= 5 * 7, per      # a handful of lobbies per chain and tick
 
 
+def test_gpu_team_path_on_a_starving_stream_pass_kernels_only(gpu_cls, oracle_cls, monkeypatch):
+    """The same stream without kt_late and without kt_f2 (MM_TEAM_LATE=0, MM_TEAM_F2=0): every pass of every tick is ONE
+    kt_fc launch — chasers, kt_f's chunks and emitters side by side — and every tick ends on a pass that seats nobody,
+    which the chaser finishes in microseconds while kt_f's workgroups are still being dispatched (the end of a chain
+    beside a running kt_f: where a workgroup must stay or leave as a whole).  100 ticks, cancels every other one."""
+    from helpers import run_starving_team_stream
+    monkeypatch.setenv("MM_TEAM_LATE", "0")
+    monkeypatch.setenv("MM_TEAM_F2", "0")
+    per, depth = run_starving_team_stream(gpu_cls, oracle_cls, preload=120_000, ticks=100, per_tick=300, cancels=15, seed=12)
+    assert depth.min() >= 4096 and sum(per) > 0, (depth, per)
+
+
 def test_gpu_device_resident_enqueue(gpu_cls, oracle_cls):
     """mm_enqueue_device: inputs already in HBM (the benchmark path) == host-pointer path."""
     import torch
