@@ -942,6 +942,13 @@ struct mm_engine {
     uint32_t* d_pk_bitsp[2];
     uint32_t* d_pk_headp[2];
     bool pair_fused;           // MM_PAIR_FUSED=0: three launches per round instead of one (A/B testing)
+    bool pair_persist;         // MM_PAIR_PERSIST=0: never several passes per launch (kp_rounds); one launch per pass as before (A/B)
+    uint32_t pair_ptiles;      // MM_PAIR_PTILES: tiles of the longest chain a kp_rounds batch may have (one workgroup per CU of ONE XCD: 32)
+    uint32_t pair_pcool;       // batches for which kp_rounds stays off after a launch that gave up (a time-out: somebody else holds the CUs)
+    uint32_t pair_pstops;      // launches that gave up so far (diagnostics)
+    uint32_t pair_pinject;     // MM_PAIR_PINJECT: PairParams.pinject (tests)
+    uint32_t pair_ptimeout[2]; // MM_PAIR_PTIMEOUT_US: what a workgroup waits at the first / at a later barrier, in 100 MHz ticks
+    unsigned long long* d_pk_pbar;   // [group] arrival words, then [group] XCD masks (one allocation)
     uint32_t round_ctr;
     uint32_t* d_pk_tilectl;
     uint32_t* d_pack;          // the packed match list of a small tick (k_pack_results)
@@ -1263,6 +1270,7 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     for (int b = 0; b < 2; ++b) { (void)hipFree(e->d_pk_exa[b]); (void)hipFree(e->d_pk_bitsp[b]); (void)hipFree(e->d_pk_headp[b]); }
     (void)hipFree(e->d_pk_tilectl);
     (void)hipFree(e->d_pk_grec);
+    (void)hipFree(e->d_pk_pbar);
     (void)hipFree(e->d_pack);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_tchains) (void)hipHostFree(e->h_tchains);
@@ -1338,6 +1346,20 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* pf = getenv("MM_PAIR_FUSED");
             e->pair_fused = !(pf && pf[0] == '0');
             e->round_ctr = 0;
+            const char* pp = getenv("MM_PAIR_PERSIST");
+            e->pair_persist = !(pp && pp[0] == '0');
+            const char* ppt = getenv("MM_PAIR_PTILES");
+            e->pair_ptiles = ppt && atoi(ppt) > 0 ? (uint32_t)atoi(ppt) : 32u;
+            if (e->pair_ptiles > 32u) e->pair_ptiles = 32u;
+            const char* ppi = getenv("MM_PAIR_PINJECT");
+            e->pair_pinject = ppi ? (uint32_t)strtoul(ppi, NULL, 0) : 0u;
+            const char* pto = getenv("MM_PAIR_PTIMEOUT_US");
+            // the first barrier of a launch is where a workgroup that found no CU is waited for (another engine's launch in the
+            // way ends within a millisecond or two); behind it everybody is on the chip and only slow, never absent
+            e->pair_ptimeout[0] = (pto ? (uint32_t)strtoul(pto, NULL, 0) : 20000u) * 100u;
+            e->pair_ptimeout[1] = e->pair_ptimeout[0] * 10u;
+            e->pair_pcool = 0;
+            e->pair_pstops = 0;
             const char* pb = getenv("MM_PAIR_BATCH");
             e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 48u;   // 16 / 32 / 48 / 64 measured: 48 by 1-2 %
             if (e->pair_batch < 1u) e->pair_batch = 1u;
@@ -1432,6 +1454,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             }
             CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_pbar, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long)));
             // two tiles' worth of entries per group of PK_GS tiles, whatever the tile length of the batch
             e->pk_gstride = (uint32_t)(2u * (e->pk_stride / PK_GS) + 4u * PK_TMAX);
             CREATE_CHK(hipMalloc((void**)&e->d_pk_grec, (size_t)cfg->n_groups * e->pk_gstride * sizeof(uint4)));
@@ -1812,7 +1835,7 @@ static int results_send(mm_engine* e, const uint32_t* n_out, uint32_t L, uint32_
 // kp_round's workgroup map of a batch (PairParams.xseg): the tiles of a chain on as few XCDs as its tile count allows.
 // Up to eight chains: an XCD each, the XCDs that are left go one by one to the chain with the most tiles per XCD;
 // more chains than XCDs: longest first onto the emptiest XCD.  Returns the slots per XCD (0: no map, the plain grid).
-static uint32_t pair_xcd_map(PairParams& P, const uint32_t* tiles_of, uint32_t G)
+static uint32_t pair_xcd_map(PairParams& P, const uint32_t* tiles_of, uint32_t G, bool one_xcd = false)
 {
     memset(P.xseg, 0, sizeof(P.xseg));
     memset(P.xcnt, 0, sizeof(P.xcnt));
@@ -1826,7 +1849,7 @@ static uint32_t pair_xcd_map(PairParams& P, const uint32_t* tiles_of, uint32_t G
     if (n <= 8u) {
         uint32_t k[MM_MAX_GROUPS];
         for (uint32_t i = 0; i < n; ++i) k[i] = 1;
-        for (uint32_t spare = 8u - n; spare; --spare) {
+        for (uint32_t spare = one_xcd ? 0u : 8u - n; spare; --spare) {     // (kp_rounds: a chain's workgroups talk through ONE L2)
             uint32_t best = 0;
             for (uint32_t i = 1; i < n; ++i)
                 if ((unsigned long long)tiles_of[order[i]] * k[best] > (unsigned long long)tiles_of[order[best]] * k[i]) best = i;
@@ -1906,6 +1929,11 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     P.grec = e->d_pk_grec;
     P.gstride = e->pk_gstride;
     P.grp = 0;
+    P.pbar = e->d_pk_pbar;
+    P.pxmask = (uint32_t*)(e->d_pk_pbar + MM_MAX_GROUPS);
+    P.ptimeout0 = e->pair_ptimeout[0];
+    P.ptimeout1 = e->pair_ptimeout[1];
+    P.pinject = e->pair_pinject;
     P.out_slots = e->d_out_slots;
     P.out_score = e->d_out_score;
     P.out_pass = e->d_out_pass;
@@ -1938,6 +1966,14 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 P.bm[g] = 0;
                 P.bbuf[g] = 0;
                 if (!pc.fast || pc.stage != PS_TILED) continue;
+                if (pc.pfail) {
+                    // the last kp_rounds launch gave up on this chain (its state is committed): one launch per pass for a while.
+                    // A chain that found itself on two XCDs says the dispatch is not what the map assumes: never again.
+                    ++e->pair_pstops;
+                    e->pair_pcool = 16u;
+                    if ((pc.pfail & 0xFFu) == PF_XCD) e->pair_persist = false;
+                    if (e->pair_debug) fprintf(stderr, "[mm-pair] g%u: kp_rounds stopped (reason %u, iteration %u)\n", g, pc.pfail & 0xFFu, pc.pfail >> 8);
+                }
                 P.bm[g] = pc.m;                       // constant until the next compaction, i.e. for the whole batch
                 P.bbuf[g] = (uint8_t)pc.buf;
                 tiled = true;
@@ -1957,9 +1993,13 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             // walk costs one dependent load per tile, everything else is proportional to the tile); the
             // three-launch form of a round (MM_PAIR_FUSED=0) stays with the largest
             uint32_t tp = PK_TMAX;
+            // several passes per launch (kp_rounds) when every chain's tiles fit the CUs of one XCD
+            bool persist = e->pair_fused && e->pair_persist && !compact && (longest + PK_TMAX - 1u) / PK_TMAX <= e->pair_ptiles;
+            if (persist && e->pair_pcool) { --e->pair_pcool; persist = false; }
+            const uint32_t tiles_max = persist && e->pair_ptiles < e->pair_tiles_max ? e->pair_ptiles : e->pair_tiles_max;
             if (e->pair_fused && !e->pair_tile_fixed)
                 for (uint32_t cand = PK_TMAX / 4u; cand < PK_TMAX; cand <<= 1)    // (an eighth was measured: slower, the fixed cost of a round takes over)
-                    if ((longest + cand - 1u) / cand <= e->pair_tiles_max) { tp = cand; break; }
+                    if ((longest + cand - 1u) / cand <= tiles_max) { tp = cand; break; }
             tiles = (longest + tp - 1u) / tp;
 #define TILE_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                                              \
     do {                                                                                                                   \
@@ -1984,9 +2024,25 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 // the batch's workgroup map: a chain's tiles together on one XCD (mm_pair.inc, PairParams.xseg)
                 dim3 rgrid(tiles, G);
                 P.xslots = 0;
+                uint32_t tof[MM_MAX_GROUPS];
+                for (uint32_t g = 0; g < G; ++g) tof[g] = P.bm[g] ? (P.bm[g] + tp - 1u) / tp : 0u;
+                if (persist) {
+                    // every chain's workgroups on ONE XCD, a CU each: they talk through that XCD's L2 and must all be on the chip
+                    const uint32_t slots = pair_xcd_map(P, tof, G, true);
+                    if (slots) {
+                        P.grp = 0;
+                        HIPCHK(e, hipMemsetAsync(e->d_pk_pbar, 0, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long), e->stream));
+                        const uint32_t K = e->pair_batch, slice = MM_PERSIST_SLICE ? MM_PERSIST_SLICE : K + 1u;
+                        for (uint32_t it = 0; it <= K; it += slice)
+                            TILE_LAUNCH(kp_rounds, dim3(8u * slots), dim3(PT_THREADS), P, it, it + slice < K + 1u ? it + slice : K + 1u, K);
+                        HIPCHK(e, hipGetLastError());
+                        { int arc = results_absorb(e, M.L); if (arc) return arc; }
+                        { int src = results_send(e, sent_no, M.L, e->results_early ? MM_RESULTS_MIN_PAIR : 0xFFFFFFFFu); if (src) return src; }
+                        continue;
+                    }
+                    P.xslots = 0;
+                }
                 if (e->pair_xcd) {
-                    uint32_t tof[MM_MAX_GROUPS];
-                    for (uint32_t g = 0; g < G; ++g) tof[g] = P.bm[g] ? (P.bm[g] + tp - 1u) / tp : 0u;
                     const uint32_t slots = pair_xcd_map(P, tof, G);
                     if (slots) rgrid = dim3(8u * slots);
                 }
@@ -2367,6 +2423,14 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                     fprintf(stderr, "[mm-pair] g%u tile1 cycles/round over %u rounds (load %u route %u apply %u | repair %u build %u resolve %u publish %u)\n",
                             g, nr, hp[g].tm[0] / nr, hp[g].tm[7] / nr, hp[g].tm[9] / nr,
                             hp[g].tm[1] / nr, hp[g].tm[2] / nr, hp[g].tm[3] / nr, hp[g].tm[4] / nr);
+            }
+        for (uint32_t g = 0; g < G; ++g)
+            if (hp[g].ppass) {
+                const uint32_t nr = hp[g].ptm[5] ? hp[g].ptm[5] : 1u;
+                fprintf(stderr, "[mm-pair] g%u kp_rounds: %u passes inside persistent launches (%u launches gave up so far); tile1 cycles/pass over %u passes (barrier %u refresh %u walk+sweepA %u apply %u | detect %u items %u long %u | graph %u resolve %u publish %u | head+arrive %u) walk loop %.0f cycles, %.1f hops\n",
+                        g, hp[g].ppass, e->pair_pstops, nr, hp[g].ptm[0] / nr, hp[g].ptm[3] / nr, hp[g].ptm[6] / nr, hp[g].ptm[9] / nr, hp[g].ptm[1] / nr,
+                        hp[g].ptm[12] / nr, hp[g].ptm[2] / nr, hp[g].ptm[7] / nr, hp[g].ptm[8] / nr, hp[g].ptm[10] / nr, hp[g].ptm[4] / nr,
+                        16.0 * hp[g].ptm[13] / nr, (double)hp[g].ptm[15] / nr);
             }
         if (e->pair_tune & 0x2000u) {
             unsigned long long tested = 0, algo = 0;

@@ -75,4 +75,21 @@ static __device__ __forceinline__ uint32_t mm_xcc_id()
     return v & 0xFu;
 }
 
+// ---- what the persistent pair rounds (kp_rounds, mm_pair.inc) need ----
+// The scalar cache (read only, shared by neighbouring CUs, in front of the XCD's L2) is not refreshed by anybody's stores:
+// after a flag barrier among workgroups, before the first scalar load of what the others published.
+static __device__ __forceinline__ void tw_sinv() { asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
+// A value another workgroup of this launch has stored: past this CU's vector L1 (which nobody's stores refresh), served by the L2.
+static __device__ __forceinline__ uint32_t xld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ uint32_t xld16(const uint16_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ unsigned long long xld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// keep the result of a returning atomic alive (the returning form is what makes the wave wait for it)
+#define TW_KEEP(v) asm volatile("" ::"v"(v))
+// A workgroup's state that lives as long as its launch: LDS.  (The CPU shim of the tests runs the workgroups of a launch one
+// after another, so it runs a persistent launch as one launch per pass and keeps this state per workgroup between them.)
+#define MM_RESIDENT(Type, var) __shared__ Type var
+#define MM_RESIDENT_FRESH(var) ((void)0)      // a new launch: LDS holds whatever the CU's last tenant left (the shim poisons it)
+// iterations of kp_rounds per launch: 0 = the whole batch in ONE launch (what the kernel is for)
+#define MM_PERSIST_SLICE 0u
+
 #endif

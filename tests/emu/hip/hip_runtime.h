@@ -111,6 +111,7 @@ template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 template <class T> static inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
+template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 
 void emu_launch(emu_dim3 grid, emu_dim3 block, const std::function<void()>& body);
 

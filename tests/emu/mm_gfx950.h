@@ -13,4 +13,20 @@ static inline void tw_store_wait() {}
 // workgroups run one after another here: the ones that wait for others of their launch come last
 #define MM_WAITERS_FIRST 0
 #define MM_WAVES_PER_SIMD(n)
+// kp_rounds (mm_pair.inc): no caches to get past here; the workgroup-resident state of a persistent launch is kept per
+// workgroup across the launches the shim cuts it into (workgroups run one after another: one pass per launch)
+static inline void tw_sinv() {}
+static inline uint32_t xld(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+static inline uint32_t xld16(const uint16_t* p) { return *(const volatile uint16_t*)p; }
+static inline unsigned long long xld64(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
+#define TW_KEEP(v) ((void)(v))
+#include <map>
+#define MM_RESIDENT(Type, var)                                                              \
+    static std::map<unsigned long long, Type*> var##_all;                                   \
+    Type*& var##_p = var##_all[((unsigned long long)blockIdx.y << 32) | blockIdx.x];        \
+    if (!var##_p) var##_p = new Type();                                                     \
+    Type& var = *var##_p
+// the first thread of a workgroup runs first here: poison before anybody has written (a real launch starts on garbage)
+#define MM_RESIDENT_FRESH(var) do { if (threadIdx.x == 0) memset(&(var), 0xA5, sizeof(var)); } while (0)
+#define MM_PERSIST_SLICE 1u
 #endif
