@@ -66,9 +66,11 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def load_traffic(path, players, mode):
+def load_traffic(path, players, mode, detail=None):
     """PMC traffic of one tick from profiles/ — only if it was measured on THESE kernel sources
-    and this workload; otherwise (None, why)."""
+    and this workload; otherwise (None, why).  `detail` (a dict) receives who owns the bytes: the three kernels with
+    the most traffic per tick (FETCH_SIZE doubled + WRITE_SIZE, as the total) and, when the file holds it, the predicate
+    tests the kernels physically performed (MM_PAIR_TUNE=0x2000 counter, a run of its own)."""
     try:
         with open(path) as f:
             tj = json.load(f)
@@ -79,19 +81,28 @@ def load_traffic(path, players, mode):
     if tj.get("source_hash") != kernel_source_hash():
         return None, "PMC file %s was measured on other kernel sources (hash %s, now %s): re-run tools/make_traffic.py" % (
             os.path.basename(path), tj.get("source_hash"), kernel_source_hash())
+    if detail is not None:
+        per = tj.get("per_kernel_kb_per_tick") or {}
+        rows = sorted(((2.0 * v.get("fetch_raw", 0.0) + v.get("write_raw", 0.0)) * 1024.0, k, v) for k, v in per.items())
+        detail["traffic_by_kernel"] = [{"kernel": k, "bytes_per_tick": b, "dispatches_per_tick": v.get("dispatches_per_tick")}
+                                       for b, k, v in reversed(rows[-3:])]
+        detail["predicate_tests_physical"] = tj.get("predicate_tests_physical")
     return tj.get("walk_hbm_bytes_per_tick"), None
 
 
 def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passes_max, traffic,
-                   boundary_us=None, traffic_note=None):
+                   boundary_us=None, traffic_note=None, traffic_detail=None):
     """The `roofline` object of the bench line (pure arithmetic; tests/test_bench_line.py).
     SURVEY.md §8(d): achieved = algorithmic bytes / walk time, with its mandatory companions —
     (i) physical HBM GB/s (PMC traffic / walk time), (ii) the compulsory bytes of a tick
     (every player read once, 12 B, and written out once, 8 B) and how close the whole step is
     to streaming just those, (iii) the tile width of the dominant kernel — and the latency
     ceiling of a chain of dependent passes (passes x one kernel boundary)."""
-    walk_name = ("pair walk: kp_nx_init + kp_round x rounds + kp_late + kp_finish"
-                 if mode == "1v1" else "team walk: (kt_build + kt_f + kt_chase + kt_emit) x passes")
+    walk_name = ("pair walk: kp_nx_init + kp_rounds (a batch of passes per launch, tiles LDS resident; kp_round, one launch "
+                 "per pass, while a chain does not fit one XCD and as its fallback) + kp_late + kp_finish"
+                 if mode == "1v1" else
+                 "team walk: kt_build + per pass ONE launch kt_fc (kt_f, the chase and the emitters side by side; the first 32 "
+                 "lobby-rich passes kt_f + kt_f2 + kt_chase<1> with its emitters) + kt_late (the last passes in one launch)")
     achieved = pairs * bytes_per_pair / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
     compulsory = float(players) * (12 + 8)
     floor_ms = passes_max * boundary_us * 1e-3 if boundary_us else None
@@ -121,6 +132,10 @@ def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passe
     }
     if traffic is None and traffic_note:
         out["traffic_note"] = traffic_note
+    if traffic is not None:
+        out["traffic_over_algorithmic"] = traffic / (pairs * bytes_per_pair) if pairs else None
+    out["traffic_by_kernel"] = (traffic_detail or {}).get("traffic_by_kernel")
+    out["predicate_tests_physical"] = (traffic_detail or {}).get("predicate_tests_physical")
     return out
 
 
@@ -225,7 +240,7 @@ def measure_boundary_us(torch, n=400):
         return None
 
 
-def concurrent_pools(make_engine, pools, steps, make_inputs):
+def concurrent_pools(make_engine, pools, steps, make_inputs, digest_of=None, expected=None):
     """Secondary leg: the walk is bound by the latency of its passes and keeps well under half of the CUs
     busy, so independent pools (other regions / shards of a service) on engines of their own
     (own stream, own device memory: include/mm_engine.h) overlap.  `pools` host threads, one
@@ -235,6 +250,7 @@ def concurrent_pools(make_engine, pools, steps, make_inputs):
     engines = [make_engine() for _ in range(pools)]
     inputs = [make_inputs(k) for k in range(pools)]
     matched = [0] * pools
+    lasts = [None] * pools
     errors = []
     start = threading.Barrier(pools + 1)
 
@@ -248,7 +264,8 @@ def concurrent_pools(make_engine, pools, steps, make_inputs):
             for _ in range(steps):
                 eng.reset()
                 eng.enqueue_device(d_rating, d_cons)
-                matched[k] += int(eng.tick(0).stats["players_matched"])
+                lasts[k] = eng.tick(0)
+                matched[k] += int(lasts[k].stats["players_matched"])
         except Exception as ex:                           # report, never hang the barrier
             errors.append(repr(ex))
             start.abort()
@@ -268,8 +285,16 @@ def concurrent_pools(make_engine, pools, steps, make_inputs):
         e.close()
     if errors:
         return {"pools": pools, "error": errors[0]}
+    # every pool's LAST tick, walked while the other engines were ticking, against the oracle's digest of that seeded pool
+    exact = None
+    if digest_of is not None and expected is not None:
+        exact = []
+        for k in range(pools):
+            want = expected(k)
+            exact.append((digest_of(lasts[k]) == want) if want else None)
     return {"pools": pools, "steps": steps, "value": sum(matched) / elapsed, "unit": "matched players/s",
-            "ms_per_step_per_pool": elapsed / steps * 1e3,
+            "ms_per_step_per_pool": elapsed / steps * 1e3, "exact_per_pool": exact,
+            "ok": (all(x for x in exact) if exact and all(x is not None for x in exact) else None),
             "note": "k independent pools on one GPU, one engine and stream each; not the headline workload "
                     "(measured sweet spot: 2 pools, profiles/r02_concurrent_pools_*.json)"}
 
@@ -507,10 +532,11 @@ def main():
                "exact": (union_digest(dg) == want) if want else None,
                "exactness": {"emission_digest": union_digest(dg), "oracle_digest": want, "key": key}}
         if traffic_path:
-            traffic, tnote = load_traffic(traffic_path, n, w["mode"])
+            tdet = {}
+            traffic, tnote = load_traffic(traffic_path, n, w["mode"], tdet)
             # (the block itself is made at the end of the run, when the kernel boundary has been measured)
             out["_roofline_args"] = (w["mode"], float(l.stats["pairs"]), w["bytes_per_pair"], walk_ms, step_ms, n,
-                                     int(l.stats["passes_max"]), traffic, tnote)
+                                     int(l.stats["passes_max"]), traffic, tnote, tdet)
         return out
 
     # The kernel-boundary micro-measurement runs LAST (rank 0): it captures a graph on a side stream of torch's, and that
@@ -546,8 +572,9 @@ def main():
         key = workload_key(args.mode, n, wl["window"], args.dist)
         want = expected_digest(key)
         traffic, tnote = (None, "PMC traffic is per single-GPU tick; not collected for the sharded run")
+        tdet = {}
         if world == 1:
-            traffic, tnote = load_traffic(args.traffic_json or tdefault, n, args.mode)
+            traffic, tnote = load_traffic(args.traffic_json or tdefault, n, args.mode, tdet)
         step_ms = elapsed_max / args.steps * 1e3
         line = {
             "metric": "matched players/sec over 1M-player pool" if world == 1 else
@@ -594,7 +621,7 @@ def main():
             "roofline": None,
         }
         main_roofline_args = (args.mode, pairs, wl["bytes_per_pair"], slow["walk_ms"], step_ms, n,
-                              max(p["passes_max"] for p in parts), traffic, tnote)
+                              max(p["passes_max"] for p in parts), traffic, tnote, tdet)
         if world == 1 and not args.no_cpu_baseline:
             cfg_cpu = make_config(wl["modes"], capacity=pow2(n), device=local_rank, timing=False)
             line["cpu_baseline"] = cpu_baseline(cfg_cpu, rating, cons, args.mode, budget_s=args.cpu_baseline_seconds)
@@ -664,8 +691,13 @@ def main():
                     r, c = make_pool(n, seed=101 + k, dist=args.dist, **wl["pool_kw"])
                     return torch.from_numpy(r).cuda(), torch.from_numpy(c.view(np.int32)).cuda()
 
-                line["concurrent_pools"] = concurrent_pools(lambda: Engine(ccfg), args.concurrent_pools,
-                                                            max(2, min(args.steps, 20)), pool_inputs)
+                def pool_digest(m):
+                    # a fresh pool's slot handles are its arrival indices (mm_reset + one enqueue)
+                    return union_digest(tick_digests(0, ccfg.n_groups, m.slots.astype(np.int64), m.group))
+
+                line["concurrent_pools"] = concurrent_pools(
+                    lambda: Engine(ccfg), args.concurrent_pools, max(2, min(args.steps, 20)), pool_inputs, pool_digest,
+                    lambda k: expected_digest(workload_key(args.mode, n, wl["window"], args.dist, seed=101 + k)))
         else:
             # the N=1 point of this very pool, on rank 0 alone (the others wait at the barrier): the speed-up of
             # the sharded run is measured inside ONE launch of bench.py, from the gathered per-rank records
@@ -735,10 +767,10 @@ def main():
     if rank == 0:
         boundary_us = None if args.no_boundary else measure_boundary_us(torch)
         a = main_roofline_args
-        line["roofline"] = roofline_block(*a[:8], boundary_us, a[8])
+        line["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9] if len(a) > 9 else None)
         if "cfg3" in line and "_roofline_args" in line["cfg3"]:
             a = line["cfg3"].pop("_roofline_args")
-            line["cfg3"]["roofline"] = roofline_block(*a[:8], boundary_us, a[8])
+            line["cfg3"]["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9] if len(a) > 9 else None)
         for leg in ("shared_pool_n1",):
             if leg in line:
                 line[leg].pop("_roofline_args", None)

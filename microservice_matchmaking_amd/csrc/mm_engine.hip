@@ -947,6 +947,7 @@ struct mm_engine {
     uint32_t pair_pcool;       // batches for which kp_rounds stays off after a launch that gave up (a time-out: somebody else holds the CUs)
     uint32_t pair_pstops;      // launches that gave up so far (diagnostics)
     uint32_t pair_pinject;     // MM_PAIR_PINJECT: PairParams.pinject (tests)
+    uint32_t pair_pbatch;      // MM_PAIR_PBATCH: passes per kp_rounds launch at most (it ends earlier when the longest chain wants its compaction)
     uint32_t pair_ptimeout[2]; // MM_PAIR_PTIMEOUT_US: what a workgroup waits at the first / at a later barrier, in 100 MHz ticks
     unsigned long long* d_pk_pbar;   // [group] arrival words, then [group] XCD masks (one allocation)
     uint32_t round_ctr;
@@ -1360,6 +1361,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_ptimeout[1] = e->pair_ptimeout[0] * 10u;
             e->pair_pcool = 0;
             e->pair_pstops = 0;
+            const char* ppb = getenv("MM_PAIR_PBATCH");
+            e->pair_pbatch = ppb && atoi(ppb) > 0 ? (uint32_t)atoi(ppb) : 96u;
             const char* pb = getenv("MM_PAIR_BATCH");
             e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 48u;   // 16 / 32 / 48 / 64 measured: 48 by 1-2 %
             if (e->pair_batch < 1u) e->pair_batch = 1u;
@@ -1454,7 +1457,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             }
             CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_pbar, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long)));
+            CREATE_CHK(hipMalloc((void**)&e->d_pk_pbar, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long) + 64u));
             // two tiles' worth of entries per group of PK_GS tiles, whatever the tile length of the batch
             e->pk_gstride = (uint32_t)(2u * (e->pk_stride / PK_GS) + 4u * PK_TMAX);
             CREATE_CHK(hipMalloc((void**)&e->d_pk_grec, (size_t)cfg->n_groups * e->pk_gstride * sizeof(uint4)));
@@ -1934,6 +1937,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     P.ptimeout0 = e->pair_ptimeout[0];
     P.ptimeout1 = e->pair_ptimeout[1];
     P.pinject = e->pair_pinject;
+    P.pyield = (uint32_t*)(e->d_pk_pbar + MM_MAX_GROUPS) + MM_MAX_GROUPS;
     P.out_slots = e->d_out_slots;
     P.out_score = e->d_out_score;
     P.out_pass = e->d_out_pass;
@@ -1966,7 +1970,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 P.bm[g] = 0;
                 P.bbuf[g] = 0;
                 if (!pc.fast || pc.stage != PS_TILED) continue;
-                if (pc.pfail) {
+                if (pc.pfail && (pc.pfail & 0xFFu) != PF_YIELD) {
                     // the last kp_rounds launch gave up on this chain (its state is committed): one launch per pass for a while.
                     // A chain that found itself on two XCDs says the dispatch is not what the map assumes: never again.
                     ++e->pair_pstops;
@@ -1989,6 +1993,28 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 if (!e->r_based) results_set_bases(e, bf, M.L);
             }
             if (!tiled) break;
+            // kp_rounds wants a chain within `pair_ptiles` tiles, and a pass costs in proportion to the tile length: a chain whose
+            // QUEUED players would fit the tiles of a shorter length (or kp_rounds at all) while its index space does not is
+            // compacted now rather than at 75 % alive.  Only the longest chain decides the tile length.
+            bool want_fit = false;
+            uint32_t yield_q = 0, yield_g = 0;
+            if (e->pair_fused && e->pair_persist && !e->pair_pcool && !compact && !e->pair_tile_fixed) {
+                uint32_t gl = 0;
+                for (uint32_t g = 1; g < G; ++g)
+                    if (P.bm[g] > P.bm[gl]) gl = g;
+                const PairChain& pc = e->h_pchains[gl];
+                if (P.bm[gl]) {
+                    // the capacity the chain's index space has to get under for the next shorter tile length (or for kp_rounds)
+                    uint32_t capq = e->pair_ptiles * PK_TMAX;
+                    for (uint32_t tlen = PK_TMAX; tlen >= PK_TMAX / 4u && pc.m <= e->pair_ptiles * tlen; tlen >>= 1) capq = e->pair_ptiles * (tlen >> 1);
+                    if (pc.m <= e->pair_ptiles * (PK_TMAX / 4u)) capq = PL_MAX - 1u;          // shortest tiles already: next is kp_late
+                    if (pc.qlen <= capq && pc.m > capq && capq >= PL_MAX) {
+                        hipLaunchKernelGGL(kp_ask_compact, dim3(G), dim3(64), 0, e->stream, P, 1u << gl);
+                        compact = true;
+                    } else if (pc.m > e->pair_ptiles * PK_TMAX) want_fit = true;      // not yet within kp_rounds' reach: a short batch
+                    else { yield_q = capq; yield_g = gl; }
+                }
+            }
             // tile length of this batch: the smallest that keeps the longest chain within PK_TILES_MAX tiles (the
             // walk costs one dependent load per tile, everything else is proportional to the tile); the
             // three-launch form of a round (MM_PAIR_FUSED=0) stays with the largest
@@ -2031,8 +2057,11 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                     const uint32_t slots = pair_xcd_map(P, tof, G, true);
                     if (slots) {
                         P.grp = 0;
-                        HIPCHK(e, hipMemsetAsync(e->d_pk_pbar, 0, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long), e->stream));
-                        const uint32_t K = e->pair_batch, slice = MM_PERSIST_SLICE ? MM_PERSIST_SLICE : K + 1u;
+                        for (uint32_t g = 0; g < G; ++g) P.pyq[g] = 0;
+                        P.pyq[yield_g] = yield_q;
+                        HIPCHK(e, hipMemsetAsync(e->d_pk_pbar, 0, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long) + 64u, e->stream));
+                        // (the batch ends by itself when the longest chain can be compacted into shorter tiles: it may be long)
+                        const uint32_t K = e->pair_pbatch, slice = MM_PERSIST_SLICE ? MM_PERSIST_SLICE : K + 1u;
                         for (uint32_t it = 0; it <= K; it += slice)
                             TILE_LAUNCH(kp_rounds, dim3(8u * slots), dim3(PT_THREADS), P, it, it + slice < K + 1u ? it + slice : K + 1u, K);
                         HIPCHK(e, hipGetLastError());
@@ -2050,7 +2079,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 TILE_LAUNCH(kp_round, rgrid, dim3(PT_THREADS), P, r, 1u);
                 ++r;
                 if (P.grp) TILE_LAUNCH(kp_group, dim3(ngr, G), dim3(1024), P, r);
-                for (uint32_t b = 0; b < e->pair_batch; ++b) {
+                for (uint32_t b = 0; b < (want_fit && e->pair_batch > 12u ? 12u : e->pair_batch); ++b) {
                     TILE_LAUNCH(kp_round, rgrid, dim3(PT_THREADS), P, r, 0u);
                     ++r;
                     if (P.grp) TILE_LAUNCH(kp_group, dim3(ngr, G), dim3(1024), P, r);
@@ -2427,7 +2456,7 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
         for (uint32_t g = 0; g < G; ++g)
             if (hp[g].ppass) {
                 const uint32_t nr = hp[g].ptm[5] ? hp[g].ptm[5] : 1u;
-                fprintf(stderr, "[mm-pair] g%u kp_rounds: %u passes inside persistent launches (%u launches gave up so far); tile1 cycles/pass over %u passes (barrier %u refresh %u walk+sweepA %u apply %u | detect %u items %u long %u | graph %u resolve %u publish %u | head+arrive %u) walk loop %.0f cycles, %.1f hops\n",
+                fprintf(stderr, "[mm-pair] g%u kp_rounds: %u passes inside persistent launches (%u launches gave up so far); tile1 cycles/pass over %u passes (barrier %u fast hops %u walk+sweepA %u apply %u | detect %u items %u long %u | graph %u resolve %u publish %u | head+arrive %u) walk loop %.0f cycles, %.1f hops\n",
                         g, hp[g].ppass, e->pair_pstops, nr, hp[g].ptm[0] / nr, hp[g].ptm[3] / nr, hp[g].ptm[6] / nr, hp[g].ptm[9] / nr, hp[g].ptm[1] / nr,
                         hp[g].ptm[12] / nr, hp[g].ptm[2] / nr, hp[g].ptm[7] / nr, hp[g].ptm[8] / nr, hp[g].ptm[10] / nr, hp[g].ptm[4] / nr,
                         16.0 * hp[g].ptm[13] / nr, (double)hp[g].ptm[15] / nr);

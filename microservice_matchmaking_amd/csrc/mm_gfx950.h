@@ -85,6 +85,51 @@ static __device__ __forceinline__ uint32_t xld16(const uint16_t* p) { return __h
 static __device__ __forceinline__ unsigned long long xld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // keep the result of a returning atomic alive (the returning form is what makes the wave wait for it)
 #define TW_KEEP(v) asm volatile("" ::"v"(v))
+// The walk's fast hops (kp_rounds), tight: from the cursor position p with the REC there (rr), follow "exit anchor whose partner
+// is still queued" from tile to tile while the partner lies BELOW position `lim` — per hop ONE round trip through the scalar cache
+// (the partner's bitmap word and the REC behind the partner) and two dozen scalar instructions; the compiler's version of the same
+// loop, with the own tile's bookkeeping inside, takes 45 and four taken branches.  k counts the lobbies on the way.
+// Ends at the first hop that is not of that kind (p, rr describe it): the caller's general code takes it from there.
+// REC layout (mm_pair.inc, rec_make): kind << 30 | lobbies inside the tile << 17 | landing position in the tile + 1; kind 1 = partner.
+static __device__ __forceinline__ void tw_hops(const uint32_t* bits, const uint32_t* rec, uint32_t m, uint32_t tmask, uint32_t lim,
+                                               uint32_t& p, uint32_t& rr, uint32_t& k)
+{
+    uint32_t t0, t1, tb, nxt, q, bw, r2;
+    asm volatile(
+        ".Ltw_top_%=:\n\t"
+        "s_lshr_b32 %[t0], %[rr], 30\n\t"
+        "s_cmp_lg_u32 %[t0], 1\n\t"
+        "s_cbranch_scc1 .Ltw_end_%=\n\t"
+        "s_and_b32 %[tb], %[p], %[tmask]\n\t"
+        "s_and_b32 %[t0], %[rr], 0x1ffff\n\t"
+        "s_add_u32 %[nxt], %[tb], %[t0]\n\t"
+        "s_cmp_gt_u32 %[nxt], %[lim]\n\t"
+        "s_cbranch_scc1 .Ltw_end_%=\n\t"
+        "s_cmp_ge_u32 %[nxt], %[m]\n\t"
+        "s_cbranch_scc1 .Ltw_end_%=\n\t"
+        "s_add_u32 %[q], %[nxt], -1\n\t"
+        "s_lshr_b32 %[t0], %[q], 5\n\t"
+        "s_lshl_b32 %[t0], %[t0], 2\n\t"
+        "s_lshl_b32 %[t1], %[nxt], 2\n\t"
+        "s_load_dword %[bw], %[bits], %[t0]\n\t"
+        "s_load_dword %[r2], %[rec], %[t1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_lshr_b32 %[bw], %[bw], %[q]\n\t"
+        "s_bitcmp1_b32 %[bw], 0\n\t"
+        "s_cbranch_scc0 .Ltw_end_%=\n\t"
+        "s_bfe_u32 %[t0], %[rr], 0xd0011\n\t"
+        "s_add_u32 %[k], %[k], %[t0]\n\t"
+        "s_add_u32 %[k], %[k], 1\n\t"
+        "s_mov_b32 %[p], %[nxt]\n\t"
+        "s_mov_b32 %[rr], %[r2]\n\t"
+        "s_branch .Ltw_top_%=\n\t"
+        ".Ltw_end_%=:\n\t"
+        : [p] "+s"(p), [rr] "+s"(rr), [k] "+s"(k), [t0] "=&s"(t0), [t1] "=&s"(t1), [tb] "=&s"(tb), [nxt] "=&s"(nxt), [q] "=&s"(q),
+          [bw] "=&s"(bw), [r2] "=&s"(r2)
+        : [bits] "s"(bits), [rec] "s"(rec), [m] "s"(m), [tmask] "s"(tmask), [lim] "s"(lim)
+        : "memory", "scc");
+}
+
 // A workgroup's state that lives as long as its launch: LDS.  (The CPU shim of the tests runs the workgroups of a launch one
 // after another, so it runs a persistent launch as one launch per pass and keeps this state per workgroup between them.)
 #define MM_RESIDENT(Type, var) __shared__ Type var

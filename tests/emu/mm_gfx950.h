@@ -3,6 +3,7 @@
 #ifndef MM_GFX950_H
 #define MM_GFX950_H
 #define TW_SINK(v) asm volatile("" ::"r"(v))
+static inline const uint32_t* tw_sptr(const uint32_t* p) { return p; }
 static inline uint32_t tw_sload(const uint32_t* p) { return *p; }
 static inline void tw_sload2(const uint32_t* p0, const uint32_t* p1, uint32_t& v0, uint32_t& v1) { v0 = *p0; v1 = *p1; }
 static inline uint32_t tw_sload_v(const uint32_t* p) { return *p; }
@@ -19,6 +20,21 @@ static inline void tw_sinv() {}
 static inline uint32_t xld(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 static inline uint32_t xld16(const uint16_t* p) { return *(const volatile uint16_t*)p; }
 static inline unsigned long long xld64(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
+// the walk's fast hops (see the product header): the same loop in plain C++
+static inline void tw_hops(const uint32_t* bits, const uint32_t* rec, uint32_t m, uint32_t tmask, uint32_t lim,
+                           uint32_t& p, uint32_t& rr, uint32_t& k)
+{
+    while ((rr >> 30) == 1u) {
+        const uint32_t tb = p & tmask;
+        const uint32_t nxt = tb + (rr & 0x1FFFFu), q = nxt - 1u;
+        if (nxt > lim || nxt >= m) break;
+        const uint32_t bw = bits[q >> 5], r2 = rec[nxt];
+        if (!((bw >> (q & 31u)) & 1u)) break;
+        k += ((rr >> 17) & 0x1FFFu) + 1u;
+        p = nxt;
+        rr = r2;
+    }
+}
 #define TW_KEEP(v) ((void)(v))
 #include <map>
 #define MM_RESIDENT(Type, var)                                                              \

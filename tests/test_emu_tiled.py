@@ -128,3 +128,16 @@ def test_product_geometry_walks_every_tile_length(oracle_cls, monkeypatch):
         assert np.array_equal(e.enqueue(rating, cons), o.enqueue(rating, cons))
         assert_same_tick(e.tick(0), o.tick(0), "50k players, one chain")
         assert_same_state(e, o, cfg, "50k players, one chain")
+
+
+@pytest.mark.parametrize("env", [{"MM_PAIR_PERSIST": "0"}, {"MM_PAIR_PINJECT": "2"}, {"MM_PAIR_PINJECT": "1"}, {"MM_PAIR_PBATCH": "5"},
+                                 {"MM_PAIR_PTILES": "3"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
+def test_tiled_rounds_stop_and_go_on(oracle_cls, monkeypatch, env):
+    """kp_rounds' ways out — the batch ends, the longest chain yields for its compaction, a workgroup declares a stop
+    (MM_PAIR_PINJECT) — and the one-launch-per-pass path it falls back to (MM_PAIR_PERSIST=0: kp_round alone), on the
+    shim: every one of them leaves the chain committed, the results are the oracle's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    two_ticks(oracle_cls, 7000, seed=21, window=40, regions=3)
+    two_ticks(oracle_cls, 5000, seed=22, window=30, regions=2, lo=0, hi=1400)

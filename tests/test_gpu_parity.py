@@ -458,3 +458,83 @@ def test_gpu_team_late_kernel_forced(gpu_cls, oracle_cls, monkeypatch, late, lat
             assert_same_state(a, b, cfg, "kt_late forced tick %d" % tick)
             live = np.setdiff1d(live, ma.slots.ravel())
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"MM_PAIR_PERSIST": "0"}, {"MM_PAIR_PINJECT": "3"}, {"MM_PAIR_PINJECT": "1"},
+                                 {"MM_PAIR_PTIMEOUT_US": "0"}, {"MM_PAIR_PBATCH": "7"}, {"MM_PAIR_PTILES": "5"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())) or "default")
+def test_gpu_pair_rounds_stop_and_go_on(gpu_cls, oracle_cls, monkeypatch, env):
+    """kp_rounds (several passes per launch, a flag barrier among a chain's workgroups) and the ways it ends: the batch
+    runs out, the longest chain yields for its compaction, a workgroup declares a stop (MM_PAIR_PINJECT: tile 1 of every
+    chain, behind the given iteration — 1: before anything has been walked), a wait runs out at once
+    (MM_PAIR_PTIMEOUT_US=0: whoever is first at a barrier gives up).  Every stop commits the chain and the host walks
+    on with one launch per pass (kp_round): same lobbies, same order as the oracle's, tick after tick with cancels."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = make_config([mode_1v1(window=25, region_filter=True)], capacity=1 << 19)
+    rng = np.random.default_rng(23)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        live_slots = np.zeros(0, np.uint32)
+        for tick in range(3):
+            rating, cons = make_pool(300000 if tick == 0 else 20000, seed=70 + tick)
+            sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+            assert np.array_equal(sa, sb)
+            live_slots = np.concatenate([live_slots, sa])
+            if tick >= 1:
+                cs = rng.choice(live_slots, size=300, replace=False)
+                a.cancel(cs)
+                b.cancel(cs)
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "rounds %s tick %d" % (env, tick), SCORE_TOL)
+            assert_same_state(a, b, cfg, "rounds %s tick %d" % (env, tick))
+            live_slots = np.setdiff1d(live_slots, ma.slots.ravel())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1v1", "5v5"])
+def test_gpu_two_engines_tick_concurrently(gpu_cls, oracle_cls, mode):
+    """Two engines on one GPU, ticking at the same time from two host threads (own streams, own device memory): the 1v1
+    pools are walked by kp_rounds launches whose workgroups wait for each other — two such launches compete for the same
+    CUs, and one that finds them taken gives up and goes on launch by launch; the 5v5 pools by kt_fc launches whose
+    chasers wait for kt_f's chunks.  Each engine against the oracle's run of its own pool, three rounds."""
+    import threading
+    if mode == "1v1":
+        modes, kw, n = [mode_1v1(window=25, region_filter=True)], {}, 400000
+    else:
+        modes, kw, n = [mode_team(5, 2, 50, (1, 1, 1, 1, 1))], {"role_weights": ROLE_WEIGHTS_5V5}, 300000
+    cfg = make_config(modes, capacity=1 << 19)
+    pools = [make_pool(n, seed=31 + k, **kw) for k in range(2)]
+    want = []
+    for rating, cons in pools:
+        with oracle_cls(cfg) as o:
+            o.enqueue(rating, cons)
+            want.append(o.tick(0))
+    engines = [gpu_cls(cfg) for _ in range(2)]
+    got = [[None] * 3 for _ in range(2)]
+    errors = []
+    start = threading.Barrier(2)
+
+    def work(k):
+        try:
+            rating, cons = pools[k]
+            for r in range(3):
+                engines[k].reset()
+                engines[k].enqueue(rating, cons)
+                start.wait(timeout=120)
+                got[k][r] = engines[k].tick(0)
+        except Exception as ex:                       # never leave the other thread at the barrier
+            errors.append(repr(ex))
+            start.abort()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in engines:
+        e.close()
+    assert not errors, errors
+    for k in range(2):
+        for r in range(3):
+            assert_same_tick(got[k][r], want[k], "engine %d round %d" % (k, r), SCORE_TOL)

@@ -33,10 +33,14 @@ from oracle.oracle import OracleEngine, build  # noqa: E402
 
 WORKLOADS = [("1v1", 1_000_000, "uniform"), ("1v1", 1_000_000, "normal"), ("1v1", 10_000_000, "uniform"),
              ("5v5", 1_000_000, "uniform"), ("5v5", 1_000_000, "normal"), ("5v5", 10_000_000, "uniform"),
-             ("1v1", 12_000, "uniform"), ("5v5", 12_000, "uniform"), ("1v1", 20_000, "uniform"), ("5v5", 20_000, "uniform")]
+             ("1v1", 12_000, "uniform"), ("5v5", 12_000, "uniform"), ("1v1", 20_000, "uniform"), ("5v5", 20_000, "uniform"),
+             # bench.py's concurrent_pools leg: pool k of the leg is seeded 101 + k (up to four pools)
+             ("1v1", 1_000_000, "uniform", 101), ("1v1", 1_000_000, "uniform", 102), ("1v1", 1_000_000, "uniform", 103),
+             ("1v1", 1_000_000, "uniform", 104), ("5v5", 1_000_000, "uniform", 101), ("5v5", 1_000_000, "uniform", 102),
+             ("1v1", 12_000, "uniform", 101), ("1v1", 12_000, "uniform", 102)]
 
 
-def digest_of(mode, n, dist):
+def digest_of(mode, n, dist, seed=1):
     if mode == "1v1":
         modes, kw, window = [mode_1v1(window=25, region_filter=True)], {}, 25
     else:
@@ -45,13 +49,13 @@ def digest_of(mode, n, dist):
     while cap < n:
         cap <<= 1
     cfg = make_config(modes, capacity=cap, timing=False)
-    rating, cons = make_pool(n, seed=1, dist=dist, **kw)
+    rating, cons = make_pool(n, seed=seed, dist=dist, **kw)
     with OracleEngine(cfg) as eng:
         slots = eng.enqueue(rating, cons)
         assert slots[0] == 0 and slots[-1] == n - 1          # slot == global arrival index
         m = eng.tick(0)
         d = union_digest(tick_digests(0, cfg.n_groups, m.slots.astype(np.int64), m.group))
-    return workload_key(mode, n, window, dist), d, int(m.stats["players_matched"])
+    return workload_key(mode, n, window, dist, seed), d, int(m.stats["players_matched"])
 
 
 # (label, seconds, players/s), 10 ms ticks: bench.py's default legs, cfg-5 at its stated size, the dry runs of tests/
@@ -82,14 +86,20 @@ def main():
     build()
     out = {}
     only_stream = len(sys.argv) > 1 and sys.argv[1] == "stream"
-    if only_stream:
+    only_new = len(sys.argv) > 1 and sys.argv[1] == "new"          # only the keys the file does not hold yet
+    if only_stream or only_new:
         with open(DIGESTS) as f:
             out = json.load(f)
-    for mode, n, dist in ([] if only_stream else WORKLOADS):
-        key, d, matched = digest_of(mode, n, dist)
+    for wk in ([] if only_stream else WORKLOADS):
+        mode, n, dist = wk[:3]
+        seed = wk[3] if len(wk) > 3 else 1
+        window = 25 if mode == "1v1" else 50
+        if only_new and workload_key(mode, n, window, dist, seed) in out:
+            continue
+        key, d, matched = digest_of(mode, n, dist, seed)
         out[key] = d
         print(key, d, "matched", matched, flush=True)
-    for label, seconds, qps in STREAMS:
+    for label, seconds, qps in ([] if only_new else STREAMS):
         key, rec = stream_digest_of(label, seconds, qps)
         out[key] = rec
         print(key, rec["digest"], "matched", rec["matched"], "backlog", [sum(b) for b in rec["backlog"]], flush=True)
