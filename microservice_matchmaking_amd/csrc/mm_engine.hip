@@ -1028,9 +1028,15 @@ struct RoctxApi {
     bool tried;
 };
 static RoctxApi g_roctx = { nullptr, nullptr, false };
+static void roctx_init_once(void);
 static void roctx_init(void)
 {
-    if (g_roctx.tried) return;
+    // engines may be created from several threads (one owner each): the table is filled exactly once
+    static std::once_flag once;
+    std::call_once(once, roctx_init_once);
+}
+static void roctx_init_once(void)
+{
     g_roctx.tried = true;
     const char* on = getenv("MM_ROCTX");
     if (!on || on[0] != '1') return;
@@ -1362,7 +1368,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_pcool = 0;
             e->pair_pstops = 0;
             const char* ppb = getenv("MM_PAIR_PBATCH");
-            e->pair_pbatch = ppb && atoi(ppb) > 0 ? (uint32_t)atoi(ppb) : 96u;
+            e->pair_pbatch = ppb && atoi(ppb) > 0 ? (uint32_t)atoi(ppb) : 48u;       // 48 / 64 / 96 measured: 95.7 / 94.6 / 93.5 M matched players/s (gpurun_out/ab_r4f.jsonl)
             const char* pb = getenv("MM_PAIR_BATCH");
             e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 48u;   // 16 / 32 / 48 / 64 measured: 48 by 1-2 %
             if (e->pair_batch < 1u) e->pair_batch = 1u;

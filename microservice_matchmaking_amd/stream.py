@@ -68,47 +68,50 @@ def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=
     if realtime:
         gc.disable()
     t_start = time.perf_counter()
-    for (t_open, t_close, n, sd, ts) in schedule:
-        rating, cons = stream_batch(n, sd, mode_weights, role_weights)
-        arrival[first:first + n] = ts
-        if realtime:
-            # the period has to be over: sleep through most of it and spin only for the last stretch (a thread that spins
-            # all the time is the first one a CPU quota throttles, for tens of milliseconds at a time)
-            while True:
-                left = t_close - (time.perf_counter() - t_start)
-                if left <= 0:
-                    break
-                if left > 0.0006:
-                    time.sleep(left - 0.0004)
-        t0 = time.perf_counter()
-        try:
-            search.enqueue(rating, cons, first_global_index=first)
-        except MMError as ex:
-            if ex.status != -4:                                 # MM_ERR_FULL: fewer than n free slots in the pool
-                raise
-            # The batch is refused as a whole and nothing of it was queued (include/mm_engine.h): for the
-            # service these deliveries stay unacked in the broker (prefetch back-pressure,
-            # lib/search/worker.ex:29) until lobbies free slots.  The stream ends here and says so.
-            full_at_s = t_open
-            break
-        first += n
-        for md in range(n_modes):
-            m = search.tick(md)
-            t1 = time.perf_counter()
-            if len(m):
-                ids = search.global_ids(m)
-                flat = ids.ravel()
-                real[md].append((t1 - t_start) - arrival[flat])
-                floor[md].append(t_close - arrival[flat])
-                matched += flat.size
-                for g in np.unique(m.group):
-                    sel = np.ascontiguousarray(ids[m.group == g], dtype="<i8")
-                    hashers[(md, int(g))].update(sel.tobytes())
-                    emitted[(md, int(g))] += int(sel.shape[0])
-        tick_cost.append(time.perf_counter() - t0)
+    try:
+        for (t_open, t_close, n, sd, ts) in schedule:
+            rating, cons = stream_batch(n, sd, mode_weights, role_weights)
+            arrival[first:first + n] = ts
+            if realtime:
+                # the period has to be over: sleep through most of it and spin only for the last stretch (a thread that spins
+                # all the time is the first one a CPU quota throttles, for tens of milliseconds at a time)
+                while True:
+                    left = t_close - (time.perf_counter() - t_start)
+                    if left <= 0:
+                        break
+                    if left > 0.0006:
+                        time.sleep(left - 0.0004)
+            t0 = time.perf_counter()
+            try:
+                search.enqueue(rating, cons, first_global_index=first)
+            except MMError as ex:
+                if ex.status != -4:                                 # MM_ERR_FULL: fewer than n free slots in the pool
+                    raise
+                # The batch is refused as a whole and nothing of it was queued (include/mm_engine.h): for the
+                # service these deliveries stay unacked in the broker (prefetch back-pressure,
+                # lib/search/worker.ex:29) until lobbies free slots.  The stream ends here and says so.
+                full_at_s = t_open
+                break
+            first += n
+            for md in range(n_modes):
+                m = search.tick(md)
+                t1 = time.perf_counter()
+                if len(m):
+                    ids = search.global_ids(m)
+                    flat = ids.ravel()
+                    real[md].append((t1 - t_start) - arrival[flat])
+                    floor[md].append(t_close - arrival[flat])
+                    matched += flat.size
+                    for g in np.unique(m.group):
+                        sel = np.ascontiguousarray(ids[m.group == g], dtype="<i8")
+                        hashers[(md, int(g))].update(sel.tobytes())
+                        emitted[(md, int(g))] += int(sel.shape[0])
+            tick_cost.append(time.perf_counter() - t0)
+    finally:
+        # whatever ends the loop (a refused batch is handled above; a failed tick, Ctrl-C): the interpreter gets its collector back
+        if realtime and gc_was:
+            gc.enable()
     elapsed = time.perf_counter() - t_start
-    if realtime and gc_was:
-        gc.enable()
     depth = [search.engine.queue_depth(md).astype(np.int64) for md in range(n_modes)]
     cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0)
     return {

@@ -27,10 +27,13 @@ defmodule Matchmaking.Search.EngineOwner do
       owner (a device-to-host copy) and handed, with a copy of the slot table, to a separate process that
       serialises and writes it (`term_to_binary` of a 1M-player table would stall the 10 ms tick loop for
       hundreds of ms); when the file is in place the journal generation before it is deleted.  `init/1`
-      restores snapshot + slot table and then re-ingests the journalled payloads that were neither
-      emitted nor cancelled since (records `{:out, ids}`).  Loss window of acked players after kill -9: none.
-      What a crash CAN do is re-emit a lobby whose `{:out, _}` record had not reached the disk — the
-      reference has the same at-least-once edge between its publish (worker.ex:319) and its ack (:323);
+      restores snapshot + slot table and replays the journal IN ORDER: an `{:out, ids}` record takes out what
+      of those ids came before it — journalled deliveries and rows of the restored pool alike (those are
+      cancelled in the engine before anything is re-ingested) — and nothing that came after it.  Loss window
+      of acked players after kill -9: none.  What a crash CAN do is re-emit a lobby whose `{:out, _}` record
+      had not reached the disk — the reference has the same at-least-once edge between its publish
+      (worker.ex:319) and its ack (:323).  (An `:out` names ids, not deliveries: of two deliveries of one id
+      the replay drops both when one of them was matched.)
     * a failed tick (`{:error, _}` from `Engine.tick/2`: the engine is mid-tick and refuses everything but
       reset / restore — include/mm_engine.h, MM_ERR_STATE) STOPS the owner without a snapshot; the supervisor
       restarts it (`restart: :transient`, application.ex:8-14) and `init/1` rebuilds the pool from the last
@@ -261,13 +264,31 @@ defmodule Matchmaking.Search.EngineOwner do
               gen = String.to_integer(Path.extname(file) |> String.trim_leading(".")), gen >= state.generation, do: gen
         last = Enum.max([state.generation | generations])
         records = Enum.flat_map(Enum.sort(generations), &read_journal(journal_path(state, &1)))
-        gone = for {:out, ids} <- records, id <- ids, into: MapSet.new(), do: id
-        payloads = for {:in, rows} <- records, payload <- rows, do: payload
+        # The records IN ORDER: an {:out, id} takes out everything of that id that came before it — the journalled
+        # deliveries AND the id's rows in the restored pool (matched or cancelled after the snapshot was taken) — and
+        # nothing that came after it (a player who cancelled and queued again within the snapshot period stays).
+        {live, gone, _seq} =
+          Enum.reduce(records, {%{}, MapSet.new(), 0}, fn
+            {:in, rows}, {live, gone, seq} ->
+              Enum.reduce(rows, {live, gone, seq}, fn payload, {l, g, n} ->
+                {Map.update(l, Poison.decode!(payload)["id"], [{n, payload}], &[{n, payload} | &1]), g, n + 1}
+              end)
+            {:out, ids}, {live, gone, seq} -> {Map.drop(live, ids), Enum.into(ids, gone), seq}
+          end)
+        # at this point the id table holds the restored pool only: whoever of it has left since is cancelled in the engine
+        # (a cancelled player is never emitted, remove_inactive_players worker.ex:267-280) before anybody is re-ingested
+        for id <- gone, {_, slot} <- :ets.lookup(state.ids, id) do
+          :ok = Engine.cancel(state.engine, <<slot::little-32>>)
+          :ets.delete(state.slots, slot)
+          :ets.match_delete(state.ids, {id, slot})
+        end
+        payloads = live |> Map.values() |> List.flatten() |> Enum.sort() |> Enum.map(&elem(&1, 1))   # arrival order
         state = %{state | generation: last}
         {:ok, fd} = :file.open(journal_path(state, last), [:append, :raw, :binary])
         state = %{state | journal: fd}
-        pending = for payload <- payloads, do: {payload, :replayed, nil}
-        ingest_replayed(%{state | pending: Enum.reverse(pending)}, gone)
+        pending = for payload <- payloads, do: {payload, %{delivery_tag: nil}, :replay}
+        # ingest/1 without acks (channel :replay) and without journalling again (the records are on disk already)
+        ingest(%{state | pending: Enum.reverse(pending), journal: nil}) |> Map.put(:journal, fd)
     end
   end
 
@@ -276,14 +297,6 @@ defmodule Matchmaking.Search.EngineOwner do
       {:ok, bin} -> for <<n::32, rec::binary-size(n) <- bin>>, do: :erlang.binary_to_term(rec, [:safe])   # a torn tail is dropped
       _ -> []
     end
-  end
-
-  # ingest/1 without acks and without journalling again; players whose id left after they came in are skipped
-  defp ingest_replayed(%{pending: []} = state, _gone), do: state
-  defp ingest_replayed(state, gone) do
-    keep = for {payload, _, _} <- Enum.reverse(state.pending),
-               id = Poison.decode!(payload)["id"], not MapSet.member?(gone, id), do: {payload, %{delivery_tag: nil}, :replay}
-    ingest(%{state | pending: Enum.reverse(keep), journal: nil}) |> Map.put(:journal, state.journal)
   end
 
   # engine snapshot + slot table in ONE file, written to a temporary name and renamed — by a process of its own:
@@ -296,8 +309,9 @@ defmodule Matchmaking.Search.EngineOwner do
       owner = self()
       write = fn ->
         file = :erlang.term_to_binary({:mm_pool, 2, generation, blob, rows})
-        :ok = File.write(path <> ".tmp", file, [:sync])
-        :ok = File.rename(path <> ".tmp", path)
+        tmp = path <> ".tmp." <> Integer.to_string(generation)       # a name per generation: writers never share a file
+        :ok = File.write(tmp, file, [:sync])
+        :ok = File.rename(tmp, path)
         send(owner, {:snapshot_written, generation})
       end
       # from here on the journal of the NEW generation takes the acks; the old one stays until the file is in place
