@@ -152,6 +152,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency legs")
+    ap.add_argument("--no-saturation", action="store_true", help="skip the latency_saturation leg (1v1 stream at rising rates)")
+    ap.add_argument("--saturation-qps", default="100000,1000000,5000000,20000000", help="offered rates of the latency_saturation leg")
+    ap.add_argument("--saturation-seconds", type=float, default=1.0)
     ap.add_argument("--no-boundary", action="store_true",
                     help="skip the kernel-boundary micro-measurement (torch add kernels; tools/collect_profiles.sh "
                          "passes this so that the profiled command holds the engine's kernels only)")
@@ -392,6 +395,61 @@ def workload_key(mode, players, window, dist_name, seed=1):
 def stream_key(label, qps, seconds, tick_ms, seed=77):
     """Key of a stream leg in tests/golden/shared_pool_digests.json (label: "1v1" | "mixed")."""
     return "stream/%s/qps%d/s%g/tick%g/seed%d" % (label, qps, seconds, tick_ms, seed)
+
+
+def saturation_leg(make_search, window, tick_ms=10.0, seconds=1.0, qps_list=(100_000, 1_000_000, 5_000_000, 20_000_000), seed=77):
+    """The latency axis with the ENGINE as the bottleneck: a 1v1 stream at rising offered rates, in `tick_ms` ticks,
+    until it no longer keeps up — a tick (H2D of the period's arrivals, bucketing, the walk to quiescence, the match list
+    back) has to fit its period.  The arrivals of a leg are made before its clock starts (numpy needs longer than 10 ms
+    for 200 000 players).  `sustained` = the highest rate with every tick's cost p99 inside the period and the stream over
+    in time; the match latency there is the arrival-limited floor plus that tick cost.  The leg at the rate for which
+    tests/golden/shared_pool_digests.json holds the oracle's digest of the same schedule is checked against it."""
+    from microservice_matchmaking_amd.sharding import union_digest
+    from microservice_matchmaking_amd.stream import latency_summary, run_stream, stream_batch, stream_schedule
+    legs, sustained = [], None
+    for qps in qps_list:
+        search = make_search(stream_capacity(qps, seconds))
+        try:
+            r0, c0 = stream_batch(2000, seed)
+            search.enqueue(r0, c0)
+            search.tick(0)
+            search.engine.reset()
+            sched = stream_schedule(qps, seconds, tick_ms, seed)
+            batches = [stream_batch(n, sd) for (_, _, n, sd, _) in sched]
+            res = run_stream(search, sched, realtime=True, batches=batches)
+        finally:
+            search.close()
+        cost = np.asarray(res["tick_cost"]) * 1e3
+        lat = latency_summary(np.concatenate([x for x in res["real"]]), np.concatenate([x for x in res["floor"]]))
+        key = stream_key("1v1", qps, seconds, tick_ms, seed)
+        want = expected_digest(key)
+        kept = bool(res["elapsed"] < seconds * 1.05 and res["full_at_s"] is None and len(cost) and np.percentile(cost, 99) < tick_ms)
+        leg = {"enqueue_qps": qps, "players_per_tick": int(round(qps * tick_ms * 1e-3)), "kept_up": kept,
+               "tick_cost_ms_p50": float(np.percentile(cost, 50)) if len(cost) else None,
+               "tick_cost_ms_p99": float(np.percentile(cost, 99)) if len(cost) else None,
+               "tick_cost_ms_max": float(cost.max()) if len(cost) else None,
+               "matched_players_per_s": res["matched"] / res["elapsed"], "elapsed_s": res["elapsed"],
+               "p50_ms": lat["p50_ms"], "p99_ms": lat["p99_ms"], "floor_p99_ms": lat["floor_p99_ms"],
+               "engine_added_p99_ms": lat.get("engine_added_p99_ms"),
+               "backlog_players": int(sum(int(d.sum()) for d in res["depth"])),
+               "capacity_exhausted_at_s": res["full_at_s"]}
+        if want is not None:
+            got = union_digest(res["digests"])
+            leg["exactness"] = {"key": key, "emission_digest": got, "oracle_digest": want["digest"],
+                                "ok": bool(got == want["digest"] and res["matched"] == want["matched"])}
+        legs.append(leg)
+        if kept:
+            sustained = leg
+        else:
+            break
+    return {"mode": "1v1 +-%d, region filter" % window, "tick_ms": tick_ms, "seconds_per_leg": seconds, "legs": legs,
+            "highest_sustained_qps": sustained["enqueue_qps"] if sustained else None,
+            "tick_cost_ms_p50_there": sustained["tick_cost_ms_p50"] if sustained else None,
+            "tick_cost_ms_p99_there": sustained["tick_cost_ms_p99"] if sustained else None,
+            "p99_ms_there": sustained["p99_ms"] if sustained else None,
+            "ok": (all(l["exactness"]["ok"] for l in legs if "exactness" in l) if any("exactness" in l for l in legs) else None),
+            "note": "offered rate raised until a tick no longer fits its period: what the ENGINE sustains, beside the "
+                    "arrival-limited floors of `latency` / `latency_mixed` (BASELINE cfg-5's 100k players/s is 1 % of it)"}
 
 
 def stream_capacity(qps, seconds):
@@ -753,6 +811,11 @@ def main():
             with ShardedSearch(scfg, Engine, 0, 1) as s1:
                 line["latency"] = stream_leg(s1, None, 0, 1, args.stream_qps, args.stream_seconds, args.stream_tick_ms,
                                              "1v1 +-%d, region filter" % args.window, "1v1")
+            if not args.no_saturation:
+                line["latency_saturation"] = saturation_leg(
+                    lambda cap: ShardedSearch(make_config([w25], capacity=cap, device=local_rank, timing=False), Engine, 0, 1),
+                    args.window, tick_ms=args.stream_tick_ms, seconds=args.saturation_seconds,
+                    qps_list=tuple(int(q) for q in args.saturation_qps.split(",")))
         if args.mode == "1v1":
             # BASELINE cfg-5: 70 % 1v1 / 30 % 5v5 (roles as cfg-3), chains = (mode, group) over the ranks
             mcfg = make_config([w25, mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=scap, device=local_rank, timing=False)

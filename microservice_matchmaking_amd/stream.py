@@ -45,7 +45,7 @@ def stream_schedule(qps, seconds, tick_ms, seed):
     return out
 
 
-def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=True):
+def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=True, batches=None):
     """Drive `search` (a sharding.ShardedSearch: one engine + the chains this rank owns) through
     the schedule.  Returns a dict with per-mode latency arrays (real, floor), matched players,
     per-tick cost and a digest per chain of everything it emitted, in order."""

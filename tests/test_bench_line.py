@@ -108,7 +108,8 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--players", "12000", "--steps", "2", "--warmup", "1", "--mode", mode,
                                       "--stream-seconds", "0.1", "--stream-qps", "20000", "--cpu-baseline-seconds", "0.5",
-                                      "--concurrent-pools", "2", "--shared-players", "20000"])
+                                      "--concurrent-pools", "2", "--shared-players", "20000",
+                                      "--saturation-qps", "20000", "--saturation-seconds", "0.1"])
     out = io.StringIO()
     with redirect_stdout(out):
         bench.main()
@@ -146,6 +147,11 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     cp = d["concurrent_pools"]                      # opt-in leg: two engines, two host threads
     assert cp["pools"] == 2 and "error" not in cp and cp["value"] > 0 and cp["steps"] == 2
+    if mode == "1v1":
+        assert cp["exact_per_pool"] == [True, True] and cp["ok"] is True     # every pool's last tick against the oracle's digest
+        sat = d["latency_saturation"]                # the 1v1 stream at rising rates (here: one rate, the dry run's)
+        assert [l["enqueue_qps"] for l in sat["legs"]] == [20000] and sat["legs"][0]["exactness"]["ok"] is True
+        assert sat["ok"] is True and "highest_sustained_qps" in sat
     if mode == "1v1":
         c3 = d["cfg3"]                               # BASELINE configs[2] beside the headline, checked the same way
         assert c3["exact"] is True and "5v5" in c3["workload"] and c3["value"] > 0 and c3["steps"] >= 2

@@ -60,7 +60,9 @@ def digest_of(mode, n, dist, seed=1):
 
 # (label, seconds, players/s), 10 ms ticks: bench.py's default legs, cfg-5 at its stated size, the dry runs of tests/
 STREAMS = [("1v1", 3.0, 100_000), ("mixed", 3.0, 100_000), ("1v1", 60.0, 100_000), ("mixed", 60.0, 100_000),
-           ("1v1", 0.1, 20_000), ("mixed", 0.1, 20_000)]
+           ("1v1", 0.1, 20_000), ("mixed", 0.1, 20_000),
+           # bench.py's latency_saturation leg (1 s per rate): the rate whose run is checked against the oracle's
+           ("1v1", 1.0, 1_000_000), ("1v1", 1.0, 100_000)]
 
 
 def stream_digest_of(label, seconds, qps=100_000, tick_ms=10.0, seed=77):
@@ -99,7 +101,9 @@ def main():
         key, d, matched = digest_of(mode, n, dist, seed)
         out[key] = d
         print(key, d, "matched", matched, flush=True)
-    for label, seconds, qps in ([] if only_new else STREAMS):
+    for label, seconds, qps in STREAMS:
+        if only_new and stream_key(label, qps, seconds, 10.0) in out:
+            continue
         key, rec = stream_digest_of(label, seconds, qps)
         out[key] = rec
         print(key, rec["digest"], "matched", rec["matched"], "backlog", [sum(b) for b in rec["backlog"]], flush=True)
