@@ -950,12 +950,6 @@ struct mm_engine {
     uint32_t pair_pbatch;      // MM_PAIR_PBATCH: passes per kp_rounds launch at most (it ends earlier when the longest chain wants its compaction)
     uint32_t pair_ptimeout[2]; // MM_PAIR_PTIMEOUT_US: what a workgroup waits at the first / at a later barrier, in 100 MHz ticks
     unsigned long long* d_pk_pbar;   // [group] arrival words, then [group] XCD masks (one allocation)
-    bool pair_wave;            // MM_PAIR_WAVE=0: kp_rounds (walk, tile work, barrier one after the other) instead of kp_wave (A/B)
-    uint32_t* d_pk_rec3;       // third copies of REC / exit anchors / pass-start bitmap / head partners (kp_wave), and its flags
-    uint16_t* d_pk_exa3;
-    uint32_t* d_pk_bitsp3;
-    uint32_t* d_pk_headp3;
-    uint32_t* d_pk_pready;
     uint32_t round_ctr;
     uint32_t* d_pk_tilectl;
     uint32_t* d_pack;          // the packed match list of a small tick (k_pack_results)
@@ -1284,8 +1278,6 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     (void)hipFree(e->d_pk_tilectl);
     (void)hipFree(e->d_pk_grec);
     (void)hipFree(e->d_pk_pbar);
-    (void)hipFree(e->d_pk_rec3); (void)hipFree(e->d_pk_exa3); (void)hipFree(e->d_pk_bitsp3); (void)hipFree(e->d_pk_headp3);
-    (void)hipFree(e->d_pk_pready);
     (void)hipFree(e->d_pack);
     if (e->h_pchains) (void)hipHostFree(e->h_pchains);
     if (e->h_tchains) (void)hipHostFree(e->h_tchains);
@@ -1375,8 +1367,6 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_ptimeout[1] = e->pair_ptimeout[0] * 10u;
             e->pair_pcool = 0;
             e->pair_pstops = 0;
-            const char* pwv = getenv("MM_PAIR_WAVE");
-            e->pair_wave = !(pwv && pwv[0] == '0');
             const char* ppb = getenv("MM_PAIR_PBATCH");
             e->pair_pbatch = ppb && atoi(ppb) > 0 ? (uint32_t)atoi(ppb) : 48u;       // 48 / 64 / 96 measured: 95.7 / 94.6 / 93.5 M matched players/s (gpurun_out/ab_r4f.jsonl)
             const char* pb = getenv("MM_PAIR_BATCH");
@@ -1474,11 +1464,6 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             CREATE_CHK(hipMalloc((void**)&e->d_pk_wpre, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint16_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_tilectl, (size_t)TC_N * cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
             CREATE_CHK(hipMalloc((void**)&e->d_pk_pbar, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long) + 64u));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_rec3, gc * sizeof(uint32_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_exa3, (gc + 64) * sizeof(uint16_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_bitsp3, (size_t)cfg->n_groups * e->pk_bits_stride * sizeof(uint32_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_headp3, (size_t)cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
-            CREATE_CHK(hipMalloc((void**)&e->d_pk_pready, (size_t)cfg->n_groups * e->pk_max_tiles * sizeof(uint32_t)));
             // two tiles' worth of entries per group of PK_GS tiles, whatever the tile length of the batch
             e->pk_gstride = (uint32_t)(2u * (e->pk_stride / PK_GS) + 4u * PK_TMAX);
             CREATE_CHK(hipMalloc((void**)&e->d_pk_grec, (size_t)cfg->n_groups * e->pk_gstride * sizeof(uint4)));
@@ -1953,8 +1938,6 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     P.grec = e->d_pk_grec;
     P.gstride = e->pk_gstride;
     P.grp = 0;
-    P.rec2[2] = e->d_pk_rec3; P.exa[2] = e->d_pk_exa3; P.bitsp[2] = e->d_pk_bitsp3; P.headp[2] = e->d_pk_headp3;
-    P.pready = e->d_pk_pready;
     P.pbar = e->d_pk_pbar;
     P.pxmask = (uint32_t*)(e->d_pk_pbar + MM_MAX_GROUPS);
     P.ptimeout0 = e->pair_ptimeout[0];
@@ -2085,12 +2068,6 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                         HIPCHK(e, hipMemsetAsync(e->d_pk_pbar, 0, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long) + 64u, e->stream));
                         // (the batch ends by itself when the longest chain can be compacted into shorter tiles: it may be long)
                         const uint32_t K = e->pair_pbatch, slice = MM_PERSIST_SLICE ? MM_PERSIST_SLICE : K + 1u;
-                        if (e->pair_wave) {
-                            P.pyq[yield_g] = 0;         // (kp_wave has no mid-batch yield: its chains are not at one pass at one time)
-                            HIPCHK(e, hipMemsetAsync(e->d_pk_pready, 0, (size_t)G * e->pk_max_tiles * sizeof(uint32_t), e->stream));
-                            for (uint32_t it = 0; it <= K; it += slice)
-                                TILE_LAUNCH(kp_wave, dim3(8u * slots), dim3(PT_THREADS), P, it, it + slice < K + 1u ? it + slice : K + 1u, K);
-                        } else
                         for (uint32_t it = 0; it <= K; it += slice)
                             TILE_LAUNCH(kp_rounds, dim3(8u * slots), dim3(PT_THREADS), P, it, it + slice < K + 1u ? it + slice : K + 1u, K);
                         HIPCHK(e, hipGetLastError());
