@@ -1959,6 +1959,8 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
         hipLaunchKernelGGL(kp_nx_init, dim3((bound + seg - 1u) / seg + 1u, G), dim3(NXI_THREADS), 0, e->stream, P, seg);
     }
     HIPCHK(e, hipGetLastError());
+    uint32_t tail_no[MM_MAX_GROUPS];
+    bool tail_send = false;
     // ---- tiled rounds for the chains that do not fit one workgroup's LDS ----
     if (bound >= PL_MAX) {
         uint32_t tiles = (bound + PK_T - 1u) / PK_T + 1u;
@@ -1998,7 +2000,12 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 for (uint32_t g = 0; g < G; ++g) { bf[g] = e->h_pchains[g].before; sent_no[g] = e->h_pchains[g].fast ? e->h_pchains[g].n_out : 0u; }
                 if (!e->r_based) results_set_bases(e, bf, M.L);
             }
-            if (!tiled) break;
+            if (!tiled) {
+                // the chains' LDS-resident ends (kp_late) run next: what the tiled rounds have emitted since the last look leaves
+                // meanwhile — enqueued BEHIND kp_late's launch, below (the device never waits for the host's copy calls)
+                if (guard) { for (uint32_t g = 0; g < G; ++g) tail_no[g] = sent_no[g]; tail_send = true; }
+                break;
+            }
             // kp_rounds wants a chain within `pair_ptiles` tiles, and a pass costs in proportion to the tile length: a chain whose
             // QUEUED players would fit the tiles of a shorter length (or kp_rounds at all) while its index space does not is
             // compacted now rather than at 75 % alive.  Only the longest chain decides the tile length.
@@ -2017,8 +2024,11 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                     if (pc.qlen <= capq && pc.m > capq && capq >= PL_MAX) {
                         hipLaunchKernelGGL(kp_ask_compact, dim3(G), dim3(64), 0, e->stream, P, 1u << gl);
                         compact = true;
-                    } else if (pc.m > e->pair_ptiles * PK_TMAX) want_fit = true;      // not yet within kp_rounds' reach: a short batch
-                    else { yield_q = capq; yield_g = gl; }
+                    } else {
+                        if (pc.m > e->pair_ptiles * PK_TMAX) want_fit = true;          // not yet within kp_rounds' reach: a short batch
+                        yield_q = capq;                                                // compact (and, in kp_rounds, end the batch) at this length
+                        yield_g = gl;
+                    }
                 }
             }
             // tile length of this batch: the smallest that keeps the longest chain within PK_TILES_MAX tiles (the
@@ -2039,14 +2049,23 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
         else if (tp == PK_TMAX / 2u) hipLaunchKernelGGL(KERNEL<PK_TMAX / 2u>, GRID, BLOCK, 0, e->stream, __VA_ARGS__);     \
         else hipLaunchKernelGGL(KERNEL<PK_TMAX / 4u>, GRID, BLOCK, 0, e->stream, __VA_ARGS__);                             \
     } while (0)
+            // the four compaction kernels look at PairChain.want_compact themselves (a chain that does not want one costs them a few
+            // microseconds): they are enqueued behind EVERY batch, so a chain that ends its batch for a compaction — the 75 % rule,
+            // the yield, the fit — is compacted before the host looks again, one look per batch instead of two
+#define COMPACT_LAUNCH()                                                                                                   \
+    do {                                                                                                                   \
+        TILE_LAUNCH(kc_words, dim3(tiles, G), dim3(256), P);                                                               \
+        TILE_LAUNCH(kc_plan, dim3(G), dim3(1024), P);                                                                      \
+        TILE_LAUNCH(kc_scatter, dim3(tiles, G), dim3(1024), P);                                                            \
+        TILE_LAUNCH(kc_commit, dim3(G), dim3(1024), P);                                                                    \
+    } while (0)
             if (compact) {
-                TILE_LAUNCH(kc_words, dim3(tiles, G), dim3(256), P);
-                TILE_LAUNCH(kc_plan, dim3(G), dim3(1024), P);
-                TILE_LAUNCH(kc_scatter, dim3(tiles, G), dim3(1024), P);
-                TILE_LAUNCH(kc_commit, dim3(G), dim3(1024), P);
+                COMPACT_LAUNCH();
                 HIPCHK(e, hipGetLastError());
                 continue;                       // look at the new lengths before the next batch
             }
+            for (uint32_t g = 0; g < G; ++g) P.pyq[g] = 0;
+            P.pyq[yield_g] = yield_q;
             if (e->pair_fused) {
                 // one launch per pass; the first of a batch only prepares, the commit brings the
                 // latest parity back into the chains' committed state
@@ -2063,13 +2082,12 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                     const uint32_t slots = pair_xcd_map(P, tof, G, true);
                     if (slots) {
                         P.grp = 0;
-                        for (uint32_t g = 0; g < G; ++g) P.pyq[g] = 0;
-                        P.pyq[yield_g] = yield_q;
                         HIPCHK(e, hipMemsetAsync(e->d_pk_pbar, 0, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long) + 64u, e->stream));
                         // (the batch ends by itself when the longest chain can be compacted into shorter tiles: it may be long)
                         const uint32_t K = e->pair_pbatch, slice = MM_PERSIST_SLICE ? MM_PERSIST_SLICE : K + 1u;
                         for (uint32_t it = 0; it <= K; it += slice)
                             TILE_LAUNCH(kp_rounds, dim3(8u * slots), dim3(PT_THREADS), P, it, it + slice < K + 1u ? it + slice : K + 1u, K);
+                        COMPACT_LAUNCH();
                         HIPCHK(e, hipGetLastError());
                         { int arc = results_absorb(e, M.L); if (arc) return arc; }
                         { int src = results_send(e, sent_no, M.L, e->results_early ? MM_RESULTS_MIN_PAIR : 0xFFFFFFFFu); if (src) return src; }
@@ -2092,6 +2110,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 }
                 TILE_LAUNCH(kp_round_commit, dim3(tiles, G), dim3(256), P, r);
                 hipLaunchKernelGGL(kp_round_stage, dim3(G), dim3(64), 0, e->stream, P, r);
+                COMPACT_LAUNCH();
                 e->round_ctr = r;
             } else {
                 for (uint32_t r = 0; r < e->pair_batch; ++r) {
@@ -2100,6 +2119,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                     hipLaunchKernelGGL(kp_tile_apply, dim3(tiles, G), dim3(PA_THREADS), 0, e->stream, P);
                 }
             }
+#undef COMPACT_LAUNCH
 #undef TILE_LAUNCH
             HIPCHK(e, hipGetLastError());
             // the device is busy with the batch: now the host takes what the last look's copies brought (slots released)
@@ -2111,6 +2131,10 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     hipLaunchKernelGGL(kp_late, dim3(G), dim3(PL_THREADS), 0, e->stream, P);
     hipLaunchKernelGGL(kp_finish, dim3(G), dim3(1024), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
+    if (tail_send) {
+        { int arc = results_absorb(e, M.L); if (arc) return arc; }
+        { int src = results_send(e, tail_no, M.L, e->results_early ? MM_RESULTS_MIN_PAIR : 0xFFFFFFFFu); if (src) return src; }
+    }
     return MM_OK;
 }
 
