@@ -2165,6 +2165,14 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     P.n_released = e->d_counters;
     P.scan_cap = e->team_cap;
     P.late_bail = 4u * e->team_late + 32u;
+    {
+        const char* fw = getenv("MM_TEAM_FWAIT");
+        P.fwait = fw ? (uint32_t)strtoul(fw, NULL, 0) : (1u << 14);       // ~5 ms of polls, then the chaser helps itself
+        const char* fm = getenv("MM_TEAM_FIXMAX");
+        P.fix_max = fm ? (uint32_t)strtoul(fm, NULL, 0) : 128u;
+        const char* nw = getenv("MM_TEAM_NOWAIT");
+        P.nowait = nw ? (uint32_t)strtoul(nw, NULL, 0) : 0u;
+    }
     P.debug = e->pair_debug ? (e->team_batch == 1u ? 3u : 1u) : 0u;   // bit 1 (with MM_TEAM_BATCH=1): kt_f counts every F it writes — an atomic per thread
     P.seq = 0;
     P.n_emit = 0;
@@ -2213,11 +2221,16 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     *any = true;
     const uint32_t nch = (longest + TT_CH - 1u) / TT_CH;
     uint32_t fo_total = 0;
-    {   // kt_fc's order of kt_f's workgroups (TeamParams.fo_*): the chains by falling length, aligned at their ends
+    // kt_fc's order of kt_f's workgroups (TeamParams.fo_*): the chains that are still walked, by falling length, aligned at
+    // their ends — made again at every look of the host at the chains, so that a chain that is done costs a pass neither
+    // workgroups nor (TeamParams.act) a load
+    auto team_order = [&]() {
         uint32_t ord[MM_MAX_GROUPS], len[MM_MAX_GROUPS], K = 0;
+        P.act = 0;
         for (uint32_t g = 0; g < G; ++g) {
             const TeamChain& t = e->h_tchains[g];
-            if (!t.fast || t.m == 0u) continue;
+            if (!t.fast || t.m == 0u || t.done) continue;
+            P.act |= 1u << g;
             const uint32_t n = (t.m + TT_CH - 1u) / TT_CH;
             uint32_t at = K++;
             while (at > 0u && len[at - 1u] < n) { ord[at] = ord[at - 1u]; len[at] = len[at - 1u]; --at; }
@@ -2225,6 +2238,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             len[at] = n;
         }
         P.fo_n = K;
+        fo_total = 0;
         for (uint32_t s = 0; s < K; ++s) {
             P.fo_chain[s] = ord[s];
             P.fo_nch[s] = len[s];
@@ -2234,7 +2248,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         }
         P.fo_start[K] = fo_total;
         P.fo_dhi[K] = 0;
-    }
+    };
+    team_order();
     uint32_t ex = longest / (M.L * TE_WAVES * 2u) + 1u;
     if (ex > 256u) ex = 256u;
     hipLaunchKernelGGL(kt_pack, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
@@ -2332,6 +2347,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             team_have = true;
         }
         if (!busy) break;
+        team_order();
         if (late_now) {
             // a chain came back from kt_late (a pass seated more than late_bail lobbies): the pass kernels take over,
             // from the chain's current pass on
@@ -2355,7 +2371,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
             const TeamChain& t = e->h_tchains[g];
             const uint32_t np = t.passes + 1u;
             fprintf(stderr, "[mm-team] g%u fast %u m %u passes %u out %u left %u | cancel tick: head sat out %u, seated %u, lobby filtered %u, anchor moved %u x | "
-                    "kt_f, the middle chunk, cycles per pass: set-up %u, windows + step A %u, scans %u, long scans %u, lobbies %u, step C %u; anchors looked up per pass %u | "
+                    "kt_f, the middle chunk, cycles per pass: first loads %u, probes + lists %u, replacements %u, look-ups from scratch %u, barrier %u, step C %u; anchors at work per pass %u | "
                     "F values written %u, changed after the first pass %u | kt_chase: sub-queue entries looked at by the stored lobby's fills %u, by %u look-ups %u\n",
                     g, t.fast, t.m, t.passes, t.n_out, t.qlen,
                     t.dbg[6] & 1u, (t.dbg[6] >> 1) & 1u, (t.dbg[6] >> 2) & 1u, t.dbg[7],

@@ -41,6 +41,7 @@ struct emu_dim3 {
 };
 typedef emu_dim3 dim3;
 struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 

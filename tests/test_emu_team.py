@@ -238,3 +238,47 @@ def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused):
     rng = np.random.default_rng(16)
     with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
         random_scenario(rng, cfg, a, b, n_rounds=4, batch=1500, cancel_frac=0.05)
+
+
+@pytest.mark.parametrize("nowait,fused", [("1", "1"), ("2", "1"), ("3", "0")])
+def test_a_chaser_that_gets_no_flag_looks_the_lobby_up_itself(oracle_cls, monkeypatch, nowait, fused):
+    """kt_fc: the chaser waits a bounded number of polls (MM_TEAM_FWAIT) for the flag of a kt_f chunk — a workgroup that
+    may not have found a CU yet when somebody else's kernels hold them — and then looks the lobby up itself, which is what it
+    does for anchors beyond kt_f's horizon anyway; the emitter is told (TV_LOOKED in vis[]) not to trust kt_f's record of
+    that anchor, which may be in the making.  MM_TEAM_NOWAIT=n is the test hook: the flag of every n-th chunk never comes
+    (1: no flag at all — the chaser walks the whole tick by itself).  A late chunk is never a failed tick."""
+    from helpers import run_starving_team_stream
+    monkeypatch.setenv("MM_TEAM_NOWAIT", nowait)
+    monkeypatch.setenv("MM_TEAM_F2", "0")               # kt_fc from the first pass
+    monkeypatch.setenv("MM_TEAM_LIVE", "1")
+    monkeypatch.setenv("MM_TEAM_FUSED", fused)
+    monkeypatch.setenv("MM_TEAM_LATE", "0")
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=17, weights=W5) > 50
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=18, regions=2) > 50
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=19, lo=0, hi=900) > 20
+    per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
+                                          capacity=1 << 14)
+    assert sum(per) > 0
+
+
+@pytest.mark.parametrize("fixmax", ["0", "2", "100000"])
+def test_lobbies_mended_or_looked_up_from_scratch(oracle_cls, monkeypatch, fixmax):
+    """kt_f keeps the lobby an anchor opens on record; when members of it have left, it replaces them (the first entries
+    that fit behind the role's last member in the role's sub-queue: kt_build leaves sqi for players that left as well) —
+    unless the chunk has more than MM_TEAM_FIXMAX such replacements to make, in which case its anchors are looked up from
+    scratch, as anchors without a record always are.  0: never mend (round 3's kt_f); 2: both ways in one tick; 100000:
+    always mend.  The small geometry has records of 5-bit distances (TF_FAR_BITS): replacements that do not fit the record."""
+    from helpers import run_starving_team_stream
+    monkeypatch.setenv("MM_TEAM_FIXMAX", fixmax)
+    monkeypatch.setenv("MM_TEAM_LATE", "0")
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=31, weights=W5) > 50
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=32, regions=2) > 50
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=33, lo=0, hi=900) > 20   # narrow window: the scan cap
+    assert ticks(oracle_cls, EmuEngine, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 9000, seed=34, n_ticks=2, lo=0, hi=1400, weights=W5) > 50   # product geometry
+    per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
+                                          capacity=1 << 14)
+    assert sum(per) > 0
+    cfg = make_config([mode_team(3, 2, 400, (2, 1), region_filter=True)], capacity=1 << 13)
+    rng = np.random.default_rng(35)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        random_scenario(rng, cfg, a, b, n_rounds=4, batch=1500, cancel_frac=0.05)

@@ -433,6 +433,74 @@ def test_gpu_team_every_launch_shape_of_a_pass(gpu_cls, oracle_cls, monkeypatch,
             assert_same_state(a, b, cfg, "launch shape 3x2 tick %d" % tick)
 
 
+@pytest.mark.parametrize("env", [{"MM_TEAM_NOWAIT": "3"}, {"MM_TEAM_FWAIT": "0"}, {"MM_TEAM_FWAIT": "0", "MM_TEAM_FUSED": "0"}])
+def test_gpu_team_chaser_without_the_flag_of_a_chunk(gpu_cls, oracle_cls, monkeypatch, env):
+    """kt_fc's chaser waits a bounded number of polls for the flag of a kt_f chunk (MM_TEAM_FWAIT; a workgroup that has
+    found no CU yet because somebody else's kernels hold them) and then looks the lobby up itself and tells the emitter not
+    to trust kt_f's record of that anchor (TV_LOOKED) — a late chunk is a slower pass, never a failed tick.  On the device,
+    where the chunk's workgroup really writes its records while the emitter collects the lobby again: MM_TEAM_FWAIT=0 gives
+    up on every flag that is not up at the first look, MM_TEAM_NOWAIT=3 never sees the flag of every third chunk."""
+    monkeypatch.setenv("MM_TEAM_F2", "0")
+    monkeypatch.setenv("MM_TEAM_LIVE", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 18)
+    rng = np.random.default_rng(23)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        live_slots = np.zeros(0, np.uint32)
+        for tick in range(3):
+            rating, cons = make_pool(100000 if tick == 0 else 3000, seed=70 + tick, role_weights=ROLE_WEIGHTS_5V5)
+            sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+            assert np.array_equal(sa, sb)
+            live_slots = np.concatenate([live_slots, sa])
+            if tick >= 1:
+                cs = rng.choice(live_slots, size=150, replace=False)
+                a.cancel(cs)
+                b.cancel(cs)
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "flagless tick %d" % tick, SCORE_TOL)
+            assert_same_state(a, b, cfg, "flagless tick %d" % tick)
+            live_slots = np.setdiff1d(live_slots, ma.slots.ravel())
+    cfg = make_config([mode_team(2, 3, 400, (1, 1), region_filter=True)], capacity=1 << 17)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        rating, cons = make_pool(60000, seed=73, n_regions=3, role_weights=(3, 2))
+        assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+        assert_same_tick(a.tick(0), b.tick(0), "flagless 3x2", SCORE_TOL)
+        assert_same_state(a, b, cfg, "flagless 3x2")
+
+
+@pytest.mark.parametrize("fixmax", ["0", "24", "100000"])
+def test_gpu_team_lobbies_mended_or_looked_up_from_scratch(gpu_cls, oracle_cls, monkeypatch, fixmax):
+    """kt_f replaces the members a recorded lobby has lost (MM_TEAM_FIXMAX: how many such replacements a chunk makes
+    before it looks its anchors up from scratch instead) — 0 is round 3's kt_f, 100000 always mends, 24 does both in one
+    tick.  200k-player 5v5 pool, then arrivals + cancels; a dense 3 x 2 mode (most anchors lose a member every pass)."""
+    monkeypatch.setenv("MM_TEAM_FIXMAX", fixmax)
+    cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 19)
+    rng = np.random.default_rng(29)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        live_slots = np.zeros(0, np.uint32)
+        for tick in range(3):
+            rating, cons = make_pool(200000 if tick == 0 else 3000, seed=80 + tick, role_weights=ROLE_WEIGHTS_5V5)
+            sa, sb = a.enqueue(rating, cons), b.enqueue(rating, cons)
+            assert np.array_equal(sa, sb)
+            live_slots = np.concatenate([live_slots, sa])
+            if tick >= 1:
+                cs = rng.choice(live_slots, size=200, replace=False)
+                a.cancel(cs)
+                b.cancel(cs)
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "mend tick %d" % tick, SCORE_TOL)
+            assert_same_state(a, b, cfg, "mend tick %d" % tick)
+            live_slots = np.setdiff1d(live_slots, ma.slots.ravel())
+    cfg = make_config([mode_team(2, 3, 400, (1, 1), region_filter=True)], capacity=1 << 18)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        for tick in range(2):
+            rating, cons = make_pool(120000 if tick == 0 else 20000, seed=83 + tick, n_regions=3, role_weights=(3, 2))
+            assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+            assert_same_tick(a.tick(0), b.tick(0), "mend 3x2 tick %d" % tick, SCORE_TOL)
+            assert_same_state(a, b, cfg, "mend 3x2 tick %d" % tick)
+
+
 @pytest.mark.parametrize("late,late0", [("1000", "512"), ("2", "100000000")])
 def test_gpu_team_late_kernel_forced(gpu_cls, oracle_cls, monkeypatch, late, late0):
     """kt_late on the device far beyond its default reach: MM_TEAM_LATE=1000 hands every chain over after the first
