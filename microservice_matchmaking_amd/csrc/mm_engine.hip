@@ -2169,7 +2169,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         const char* fw = getenv("MM_TEAM_FWAIT");
         P.fwait = fw ? (uint32_t)strtoul(fw, NULL, 0) : (1u << 14);       // ~5 ms of polls, then the chaser helps itself
         const char* fm = getenv("MM_TEAM_FIXMAX");
-        P.fix_max = fm ? (uint32_t)strtoul(fm, NULL, 0) : 128u;
+        P.fix_max = fm ? (uint32_t)strtoul(fm, NULL, 0) : 0xFFFFFFFFu;   // (measured: mending always wins once a task is a quarter wave's)
         const char* nw = getenv("MM_TEAM_NOWAIT");
         P.nowait = nw ? (uint32_t)strtoul(nw, NULL, 0) : 0u;
     }
