@@ -2379,9 +2379,12 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
                     t.dbg[0], t.dbg[3], t.dbg[1]);
             if (t.lt[11])
                 fprintf(stderr, "[mm-team] g%u kt_fc's chaser: %u passes, %u lobbies by F; cycles per pass: all %u, the chase loop %u, its hops by F %u, of them on kt_f's flags %u; "
-                        "cycles per hop without the flags %u\n",
+                        "cycles per hop without the flags %u; %u look-ups, cycles each: starts %u, the roles' stretches %u, the members' records %u, seats + kills (the one a pass ends on) %u "
+                        "(with MM_TEAM_LATE=0: kt_late keeps its own timers in the same words)\n",
                         g, t.lt[11], t.lt[12], 16u * (t.lt[9] / t.lt[11]), 16u * (t.lt[10] / t.lt[11]), 16u * (t.lt[13] / t.lt[11]), 16u * (t.lt[8] / t.lt[11]),
-                        t.lt[12] ? (uint32_t)(16ull * (t.lt[13] - t.lt[8]) / t.lt[12]) : 0u);
+                        t.lt[12] ? (uint32_t)(16ull * (t.lt[13] - t.lt[8]) / t.lt[12]) : 0u,
+                        t.lt[3], t.lt[3] ? 16u * (t.lt[4] / t.lt[3]) : 0u, t.lt[3] ? 16u * (t.lt[5] / t.lt[3]) : 0u, t.lt[3] ? 16u * (t.lt[6] / t.lt[3]) : 0u,
+                        16u * (t.lt[7] / t.lt[11]));
         }
     return MM_OK;
 }
