@@ -2170,6 +2170,10 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         P.fwait = fw ? (uint32_t)strtoul(fw, NULL, 0) : (1u << 14);       // ~5 ms of polls, then the chaser helps itself
         const char* fm = getenv("MM_TEAM_FIXMAX");
         P.fix_max = fm ? (uint32_t)strtoul(fm, NULL, 0) : 0xFFFFFFFFu;   // (measured: mending always wins once a task is a quarter wave's)
+        const char* f8 = getenv("MM_TEAM_FIXT8");
+        const char* f4 = getenv("MM_TEAM_FIXT4");
+        P.fix_t8 = f8 ? (uint32_t)strtoul(f8, NULL, 0) : 10u;
+        P.fix_t4 = f4 ? (uint32_t)strtoul(f4, NULL, 0) : 64u;
         const char* nw = getenv("MM_TEAM_NOWAIT");
         P.nowait = nw ? (uint32_t)strtoul(nw, NULL, 0) : 0u;
     }

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 : > $R/$OUTF
 for SET in "$@"; do
   rm -rf /tmp/qc_$MODE
-  rocprofv3 --kernel-trace --pmc $SET -d /tmp/qc_$MODE -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stream --no-secondary --no-boundary --no-pcie --no-prediction --mode $MODE > /dev/null 2> /tmp/qc_$MODE.err
+  timeout 150 rocprofv3 --kernel-trace --pmc $SET -d /tmp/qc_$MODE -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stream --no-secondary --no-boundary --no-pcie --no-prediction --mode $MODE > /dev/null 2> /tmp/qc_$MODE.err
   DB=$(find /tmp/qc_$MODE -name "*_results.db" | head -1)
   python $R/tools/rocpd_pmc.py $DB 2>/dev/null | grep -E "kt_|kp_|kernel," >> $R/$OUTF
 done
