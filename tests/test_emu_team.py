@@ -261,8 +261,8 @@ def test_a_chaser_that_gets_no_flag_looks_the_lobby_up_itself(oracle_cls, monkey
     assert sum(per) > 0
 
 
-@pytest.mark.parametrize("fixmax", ["0", "2", "100000"])
-def test_lobbies_mended_or_looked_up_from_scratch(oracle_cls, monkeypatch, fixmax):
+@pytest.mark.parametrize("fixmax,t8,t4", [("0", "10", "64"), ("2", "10", "64"), ("100000", "10", "64"), ("100000", "0", "0"), ("100000", "0", "1000")])
+def test_lobbies_mended_or_looked_up_from_scratch(oracle_cls, monkeypatch, fixmax, t8, t4):
     """kt_f keeps the lobby an anchor opens on record; when members of it have left, it replaces them (the first entries
     that fit behind the role's last member in the role's sub-queue: kt_build leaves sqi for players that left as well) —
     unless the chunk has more than MM_TEAM_FIXMAX such replacements to make, in which case its anchors are looked up from
@@ -270,11 +270,16 @@ def test_lobbies_mended_or_looked_up_from_scratch(oracle_cls, monkeypatch, fixma
     always mend.  The small geometry has records of 5-bit distances (TF_FAR_BITS): replacements that do not fit the record."""
     from helpers import run_starving_team_stream
     monkeypatch.setenv("MM_TEAM_FIXMAX", fixmax)
+    monkeypatch.setenv("MM_TEAM_FIXT8", t8)            # replacements a wave has above which each gets eight / four lanes instead of sixteen
+    monkeypatch.setenv("MM_TEAM_FIXT4", t4)
     monkeypatch.setenv("MM_TEAM_LATE", "0")
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=31, weights=W5) > 50
+    assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=33, n_ticks=2, lo=0, hi=900) > 20   # narrow window: the scan cap
+    if fixmax != "100000" or t8 != "10":
+        return
+    # the defaults: more shapes, and the product geometry as well
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=32, regions=2) > 50
-    assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=33, lo=0, hi=900) > 20   # narrow window: the scan cap
-    assert ticks(oracle_cls, EmuEngine, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 9000, seed=34, n_ticks=2, lo=0, hi=1400, weights=W5) > 50   # product geometry
+    assert ticks(oracle_cls, EmuEngine, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 9000, seed=34, n_ticks=2, lo=0, hi=1400, weights=W5) > 50
     per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
                                           capacity=1 << 14)
     assert sum(per) > 0
