@@ -2174,6 +2174,8 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         const char* f4 = getenv("MM_TEAM_FIXT4");
         P.fix_t8 = f8 ? (uint32_t)strtoul(f8, NULL, 0) : 10u;
         P.fix_t4 = f4 ? (uint32_t)strtoul(f4, NULL, 0) : 64u;
+        const char* px = getenv("MM_TEAM_PULLX");
+        P.pull_xcd = px ? (uint32_t)strtoul(px, NULL, 0) : 1u;
         const char* nw = getenv("MM_TEAM_NOWAIT");
         P.nowait = nw ? (uint32_t)strtoul(nw, NULL, 0) : 0u;
     }

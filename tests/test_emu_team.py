@@ -230,10 +230,11 @@ def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused):
     monkeypatch.setenv("MM_TEAM_LATE", "0")
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=13, weights=W5) > 50
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=14, regions=2) > 50
-    assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=15, lo=0, hi=900) > 20   # narrow window: the scan cap
-    per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
-                                          capacity=1 << 14)
-    assert sum(per) > 0
+    if (f2, live, fused) in (("0", "1", "1"), ("0", "0", "0")):      # the shipped shape and round 2's: the scan cap and the starving stream too
+        assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=15, lo=0, hi=900) > 20   # narrow window: the scan cap
+        per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
+                                              capacity=1 << 14)
+        assert sum(per) > 0
     cfg = make_config([mode_team(3, 2, 400, (2, 1), region_filter=True)], capacity=1 << 13)
     rng = np.random.default_rng(16)
     with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
