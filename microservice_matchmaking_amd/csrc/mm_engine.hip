@@ -978,6 +978,7 @@ struct mm_engine {
     uint32_t* d_tk_fdone;      // [group][tk_chunk_stride] kt_fc: the launch (team_seq) whose kt_f chunk has stored its F
     uint32_t team_seq;         // kt_chase / kt_fc launches of this engine so far (never 0: it names a launch to its workgroups)
     uint32_t team_emit_max;    // MM_TEAM_EMIT_MAX
+    uint32_t team_split;       // MM_TEAM_SPLIT: the stored lobby's fill in kt_f's launch (the lobby-rich passes)
     bool team_live;            // MM_TEAM_LIVE: kt_f and the chase of a pass in one launch (kt_fc) where there is no kt_f2
     uint32_t* d_tk_sqi;        // [group][pk_stride] position -> sub-queue entry
     uint32_t team_rebuild;     // MM_TEAM_REBUILD: kt_build runs in the first two passes of a tick and every this many after
@@ -1384,6 +1385,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->team_fused = !(tfe && tfe[0] == '0');                     // 0: kt_emit as a launch of its own behind every chase (cfg-3: +1.3 ms per tick)
             const char* tem = getenv("MM_TEAM_EMIT_MAX");
             e->team_emit_max = tem ? (uint32_t)strtoul(tem, NULL, 0) : TC_EMIT_MAX;   // emitter workgroups per chain and launch at most
+            { const char* tsp = getenv("MM_TEAM_SPLIT"); e->team_split = tsp ? (uint32_t)strtoul(tsp, NULL, 0) : 1u; }
             if (e->team_emit_max < 1u) e->team_emit_max = 1u;
             const char* tlv = getenv("MM_TEAM_LIVE");
             e->team_live = !(tlv && tlv[0] == '0');                      // 0: kt_f and kt_chase as launches of their own in every pass (cfg-3: +0.7 ms per tick)
@@ -2293,8 +2295,11 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
                 if (++e->team_seq == 0u) e->team_seq = 1u;
                 P.seq = e->team_seq;
                 P.n_emit = e->team_fused ? n_emit : 0u;
+                P.hf_x = 0xFFFFFFFFu;
                 if (P.use_f2) {
-                    hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+                    // (the stored lobbies' fill from the heads of the queues rides in kt_f's launch: MM_TEAM_SPLIT)
+                    if (e->team_split) P.hf_x = nch;
+                    hipLaunchKernelGGL(kt_f, dim3(nch + (e->team_split ? 1u : 0u), G), dim3(TT_CH), 0, e->stream, P);
                     hipLaunchKernelGGL(kt_f2, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
                     hipLaunchKernelGGL(kt_chase<1>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
                 } else if (e->team_live) {

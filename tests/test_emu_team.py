@@ -215,9 +215,9 @@ def test_kt_late_hands_a_chain_back_after_a_rich_pass(oracle_cls, monkeypatch):
                  weights=[0.2] * 5, capacity=1 << 15) > 300
 
 
-@pytest.mark.parametrize("f2,live,fused", [("0", "1", "0"), ("0", "1", "1"), ("2", "1", "1"), ("1000", "0", "1"),
-                                           ("0", "0", "0")])
-def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused):
+@pytest.mark.parametrize("f2,live,fused,split", [("0", "1", "0", "1"), ("0", "1", "1", "1"), ("2", "1", "1", "1"), ("1000", "0", "1", "1"),
+                                                 ("1000", "0", "1", "0"), ("0", "0", "0", "1")])
+def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused, split):
     """A pass is kt_f + kt_chase + kt_emit as three launches, or kt_f and the chase in one (kt_fc: MM_TEAM_LIVE, the
     passes from MM_TEAM_F2 on), or with the emitter workgroups riding in the chase's launch (MM_TEAM_FUSED) — every
     combination must give the oracle's ticks: cancel ticks, stored lobbies, the scan cap, the starving stream.  (Under
@@ -227,6 +227,7 @@ def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused):
     monkeypatch.setenv("MM_TEAM_F2", f2)
     monkeypatch.setenv("MM_TEAM_LIVE", live)
     monkeypatch.setenv("MM_TEAM_FUSED", fused)
+    monkeypatch.setenv("MM_TEAM_SPLIT", split)         # the stored lobby's fill from the head of the queue in kt_f's launch (the passes with kt_f2) or in kt_chase's
     monkeypatch.setenv("MM_TEAM_LATE", "0")
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=13, weights=W5) > 50
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=14, regions=2) > 50

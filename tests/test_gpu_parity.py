@@ -398,8 +398,9 @@ def test_gpu_pair_second_route_level_forced(gpu_cls, oracle_cls, monkeypatch):
             live = np.setdiff1d(live, ma.slots.ravel())
 
 
-@pytest.mark.parametrize("f2,live,fused", [("0", "1", "0"), ("0", "1", "1"), ("1000", "0", "1"), ("32", "0", "0")])
-def test_gpu_team_every_launch_shape_of_a_pass(gpu_cls, oracle_cls, monkeypatch, f2, live, fused):
+@pytest.mark.parametrize("f2,live,fused,split", [("0", "1", "0", "1"), ("0", "1", "1", "1"), ("1000", "0", "1", "1"), ("1000", "0", "1", "0"),
+                                                 ("32", "0", "0", "1")])
+def test_gpu_team_every_launch_shape_of_a_pass(gpu_cls, oracle_cls, monkeypatch, f2, live, fused, split):
     """The three ways a pass of the team path is launched — kt_f / kt_chase / kt_emit one behind the other; kt_f and
     the chase in one launch (kt_fc, the chasers taking F chunk by chunk while kt_f is still at work: MM_TEAM_LIVE, from
     pass MM_TEAM_F2 on); the emitter workgroups in the chase's launch (MM_TEAM_FUSED) — on the device, where the
@@ -407,6 +408,7 @@ def test_gpu_team_every_launch_shape_of_a_pass(gpu_cls, oracle_cls, monkeypatch,
     monkeypatch.setenv("MM_TEAM_F2", f2)
     monkeypatch.setenv("MM_TEAM_LIVE", live)
     monkeypatch.setenv("MM_TEAM_FUSED", fused)
+    monkeypatch.setenv("MM_TEAM_SPLIT", split)         # the stored lobby's fill in kt_f's launch, beside its chunks (the passes with kt_f2), or in kt_chase's
     cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 19)
     rng = np.random.default_rng(17)
     with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
