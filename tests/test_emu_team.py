@@ -231,7 +231,7 @@ def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused, 
     monkeypatch.setenv("MM_TEAM_LATE", "0")
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=13, weights=W5) > 50
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=14, regions=2) > 50
-    if (f2, live, fused) in (("0", "1", "1"), ("0", "0", "0")):      # the shipped shape and round 2's: the scan cap and the starving stream too
+    if (f2, live, fused) == ("0", "1", "1"):             # the shipped shape: the scan cap and the starving stream too
         assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=15, lo=0, hi=900) > 20   # narrow window: the scan cap
         per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
                                               capacity=1 << 14)
@@ -279,9 +279,8 @@ def test_lobbies_mended_or_looked_up_from_scratch(oracle_cls, monkeypatch, fixma
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=33, n_ticks=2, lo=0, hi=900) > 20   # narrow window: the scan cap
     if fixmax != "100000" or t8 != "10":
         return
-    # the defaults: more shapes, and the product geometry as well
+    # the defaults: more shapes (the product geometry: test_team_short_chains_stay_with_k_walk, and the gpu tier)
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=32, regions=2) > 50
-    assert ticks(oracle_cls, EmuEngine, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 9000, seed=34, n_ticks=2, lo=0, hi=1400, weights=W5) > 50
     per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
                                           capacity=1 << 14)
     assert sum(per) > 0
