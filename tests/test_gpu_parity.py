@@ -608,3 +608,51 @@ def test_gpu_two_engines_tick_concurrently(gpu_cls, oracle_cls, mode):
     for k in range(2):
         for r in range(3):
             assert_same_tick(got[k][r], want[k], "engine %d round %d" % (k, r), SCORE_TOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1v1", "5v5"])
+def test_gpu_ticks_beside_a_foreign_workload(gpu_cls, oracle_cls, mode):
+    """Somebody else's kernels on the same GPU while the engine ticks: a host thread keeps a torch stream busy with matrix
+    products that fill every CU (each a few milliseconds), the engine ticks its pool three times beside them.  What waits for
+    other workgroups inside a launch — kp_rounds' tiles for each other (1v1), kt_fc's chasers for kt_f's chunks and the
+    emitters for their chasers (5v5) — finds its partners late or not on the chip; a stop or a flag that does not come is a
+    slower tick, never a failed or a different one: every tick equals the oracle's."""
+    import threading
+    import torch
+    if mode == "1v1":
+        modes, kw, n = [mode_1v1(window=25, region_filter=True)], {}, 400000
+    else:
+        modes, kw, n = [mode_team(5, 2, 50, (1, 1, 1, 1, 1))], {"role_weights": ROLE_WEIGHTS_5V5}, 300000
+    cfg = make_config(modes, capacity=1 << 19)
+    rating, cons = make_pool(n, seed=41, **kw)
+    with oracle_cls(cfg) as o:
+        o.enqueue(rating, cons)
+        want = o.tick(0)
+    stop = threading.Event()
+    launched = [0]
+
+    def hog():
+        s = torch.cuda.Stream()
+        a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        b = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        with torch.cuda.stream(s):
+            while not stop.is_set():
+                for _ in range(4):
+                    a @ b
+                    launched[0] += 1
+                s.synchronize()
+
+    th = threading.Thread(target=hog)
+    th.start()
+    try:
+        with gpu_cls(cfg) as e:
+            for r in range(3):
+                e.reset()
+                e.enqueue(rating, cons)
+                got = e.tick(0)
+                assert_same_tick(got, want, "beside a foreign workload, round %d" % r, SCORE_TOL)
+    finally:
+        stop.set()
+        th.join(timeout=60)
+    assert launched[0] > 0
