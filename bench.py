@@ -90,8 +90,35 @@ def load_traffic(path, players, mode, detail=None):
     return tj.get("walk_hbm_bytes_per_tick"), None
 
 
+# The serial critical path of a pair tick, from primitives measured on this part (cycles at 2.4 GHz; the files under profiles/):
+#   a pass inside kp_rounds   = the chain's flag barrier + its route hops at the L2-hit price
+#   a pass as a kp_round launch = a kernel boundary (measured in this run) + its hops at the price of a load from memory
+#   kp_late                   = one dependent LDS step per lobby + one per pass
+# Everything else a pass does today (the tile work: apply, repair, tables) is parallel work that COULD be hidden; this is the
+# floor of the design as built, what `frac_of_critical_path` holds the walk to.
+CRIT = {"barrier_us": 4277 / 2400.0,          # profiles/r04_pair_phase_timers.txt, g0 kp_rounds: "barrier 4277" cycles a pass
+        "hop_l2_us": 281 / 2400.0,            # a route hop whose line sits in the chain's L2 (tw_hops)
+        "hop_mem_us": 470 / 2400.0,           # profiles/r04_ubench_xwg_hop.txt: a dependent load of a line that was only stored
+        "late_step_us": 100 / 2400.0,         # the blind chase of kp_late, cycles per lobby
+        "late_pass_us": 128 / 2400.0,         # one dependent LDS round trip (the pass's careful last step)
+        "boundary_us_default": 2.4}           # kp_round to kp_round (profiles/r02_kernel_passes_1m_1v1.txt) when not measured here
+
+
+def critical_path_ms(path, boundary_us=None):
+    """(ms, parts) of the pair path's serial critical path for the tick `path` (mm_path_stats_get) describes, or (None, None)."""
+    if not path or not (path.get("paths", 0) & 2) or not path.get("crit_passes"):
+        return None, None
+    b = boundary_us if boundary_us else CRIT["boundary_us_default"]
+    rp, rh = path["crit_rounds_passes"], path["crit_rounds_hops"]
+    hops_per_pass = (rh / rp) if rp else 0.0
+    parts = {"kp_rounds": (rp * CRIT["barrier_us"] + rh * CRIT["hop_l2_us"]) * 1e-3,
+             "kp_round": path["crit_round_passes"] * (b + hops_per_pass * CRIT["hop_mem_us"]) * 1e-3,
+             "kp_late": (path["crit_late_lobbies"] * CRIT["late_step_us"] + path["crit_late_passes"] * CRIT["late_pass_us"]) * 1e-3}
+    return sum(parts.values()), parts
+
+
 def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passes_max, traffic,
-                   boundary_us=None, traffic_note=None, traffic_detail=None):
+                   boundary_us=None, traffic_note=None, traffic_detail=None, path=None):
     """The `roofline` object of the bench line (pure arithmetic; tests/test_bench_line.py).
     SURVEY.md §8(d): achieved = algorithmic bytes / walk time, with its mandatory companions —
     (i) physical HBM GB/s (PMC traffic / walk time), (ii) the compulsory bytes of a tick
@@ -120,6 +147,7 @@ def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passe
         "latency_floor_ms": floor_ms,
         "frac_of_latency_ceiling": (floor_ms / walk_ms) if (floor_ms and walk_ms > 0) else None,
         "us_per_pass": (walk_ms * 1e3 / passes_max) if passes_max else None,
+        "critical_path_ms": None, "frac_of_critical_path": None,
         "note": ("Mode R is a chain of dependent first-fit steps (%d passes of the cursor for "
                  "the longest rating group); the engine replaces the per-pair rescans by "
                  "%s, so it is bound by pass latency (kernel boundaries + LDS/VALU issue), "
@@ -130,6 +158,18 @@ def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passe
                     "per-pass F pointers (who the cursor picks after each player's lobby) "
                     "computed for every queued player at once"),
     }
+    cp, cparts = critical_path_ms(path, boundary_us)
+    if cp is not None:
+        # latency_floor_ms above is the floor of a one-launch-per-pass design and is kept for continuity with rounds 1-4;
+        # the path that runs now has no kernel boundary in most passes: this is the ceiling that applies to it
+        out["critical_path_ms"] = cp
+        out["frac_of_critical_path"] = (cp / walk_ms) if walk_ms > 0 else None
+        out["critical_path_model"] = {
+            "parts_ms": cparts, "primitives_us": {k: v for k, v in CRIT.items() if k != "boundary_us_default"},
+            "passes": {"kp_rounds": path["crit_rounds_passes"], "kp_round": path["crit_round_passes"], "kp_late": path["crit_late_passes"]},
+            "hops_in_kp_rounds": path["crit_rounds_hops"], "lobbies_in_kp_late": path["crit_late_lobbies"],
+            "what": "the chain with the most passes (rating group %d): barrier + route hops per pass inside kp_rounds, kernel boundary "
+                    "+ hops from memory per kp_round launch, one dependent LDS step per lobby and pass inside kp_late" % path["crit_group"]}
     if traffic is None and traffic_note:
         out["traffic_note"] = traffic_note
     if traffic is not None:
@@ -478,19 +518,82 @@ def expected_digest(key):
         return None
 
 
+# What `python bench.py --gpus N` re-executes once per rank when no launcher has set WORLD_SIZE (launch_ranks).  The dry
+# run of tests/test_bench_line.py points it at its own worker script (gloo + the shim engine) before it calls main().
+SELF_CMD = [sys.executable, os.path.abspath(__file__)]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` as ONE command, nobody having set WORLD_SIZE: this process becomes the launcher of N
+    ranks of itself — env rendezvous on 127.0.0.1, RANK = LOCAL_RANK = 0 .. N-1, one process per GPU, what
+    `python -m torch.distributed.run --nproc-per-node N` would set — relays rank 0's stdout (the ONE JSON line) and
+    returns the first non-zero exit code.  So a plain `--gpus 8` can never print an N = 1 number."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MM_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen(SELF_CMD + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    # a rank that dies leaves the others in a collective: end them (by their own PIDs) instead of waiting for RCCL's time-out
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    rd.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print("bench.py: rank(s) %s exited non-zero %s" % ([r for r, _ in bad], [c for _, c in bad]), file=sys.stderr)
+        return bad[0][1] if bad[0][1] > 0 else 1
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            rc = launch_ranks(args.gpus, sys.argv[1:])
+            if rc:
+                sys.exit(rc)
+            return
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        # a launcher that made another number of ranks than the line would claim: refuse, do not print a mislabelled number
+        print("bench.py: --gpus %d but WORLD_SIZE=%s — launch one rank per GPU (python -m torch.distributed.run "
+              "--nproc-per-node %d ... bench.py --gpus %d), or run `python bench.py --gpus %d` without a launcher and it "
+              "starts the ranks itself" % (args.gpus, os.environ["WORLD_SIZE"], args.gpus, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    if world > 1 and torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d wants GPU %d, this node shows %d" % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ones = torch.ones(1).cuda()
+        dist.all_reduce(ones)                       # the ranks RCCL really connected: an all-reduce of ones
+        rccl_ranks = int(ones.item())
 
     from microservice_matchmaking_amd import Engine, make_config, mode_1v1, mode_team
     from microservice_matchmaking_amd.sharding import (ChainSharding, ShardedSearch, chain_weights, rating_groups,
@@ -541,7 +644,7 @@ def main():
         sh = ChainSharding(1, cfg1.n_groups, nranks, chain_weights(cfg1, rating, cons)[0])
         grp = rating_groups(cfg1, rating)
         idx = np.nonzero(sh.chain_owner[0][grp.astype(np.int64)] == r)[0]
-        timers = {"walk": [], "bucket": [], "copy": []}
+        timers = {"walk": [], "bucket": [], "copy": [], "step": []}
         digests, last = {}, None
         elapsed = 0.0
         sync = fence if collective else torch.cuda.synchronize
@@ -561,8 +664,13 @@ def main():
         sync()
         t0 = time.perf_counter()
         if idx.size:
+            ts = t0
             for _ in range(steps):
                 first, last, est = step()
+                # (a step ends with its match list on the host: no synchronisation is added to take its time)
+                tn = time.perf_counter()
+                timers["step"].append((tn - ts) * 1e3)
+                ts = tn
                 timers["walk"].append(last.stats["walk_ms"])
                 timers["bucket"].append(est["bucket_ms"])
                 timers["copy"].append(last.stats["copy_ms"])
@@ -574,6 +682,7 @@ def main():
                 np.zeros(last.slots.shape, np.int64)
             digests = {c: d for c, d in tick_digests(0, cfg.n_groups, ids, last.group).items()
                        if sh.chain_owner[c] == r}
+            timers["path"] = eng.path_stats()        # mm_path_stats_get: the launch shapes and fall-backs of the last timed tick
             eng.close()
         return elapsed, last, timers, digests, sh, int(idx.size), (rating, cons)
 
@@ -588,13 +697,15 @@ def main():
                "unit": "matched players/s", "ms_per_step": step_ms, "steps": steps,
                "passes_max": int(l.stats["passes_max"]), "walk_ms": walk_ms, "pairs_per_step": float(l.stats["pairs"]),
                "exact": (union_digest(dg) == want) if want else None,
+               "path": tm.get("path"), "degraded": bool((tm.get("path") or {}).get("degraded")),
+               "ms_per_step_min_median_max": [float(np.min(tm["step"])), float(np.median(tm["step"])), float(np.max(tm["step"]))],
                "exactness": {"emission_digest": union_digest(dg), "oracle_digest": want, "key": key}}
         if traffic_path:
             tdet = {}
             traffic, tnote = load_traffic(traffic_path, n, w["mode"], tdet)
             # (the block itself is made at the end of the run, when the kernel boundary has been measured)
             out["_roofline_args"] = (w["mode"], float(l.stats["pairs"]), w["bytes_per_pair"], walk_ms, step_ms, n,
-                                     int(l.stats["passes_max"]), traffic, tnote, tdet)
+                                     int(l.stats["passes_max"]), traffic, tnote, tdet, tm.get("path"))
         return out
 
     # The kernel-boundary micro-measurement runs LAST (rank 0): it captures a graph on a side stream of torch's, and that
@@ -612,7 +723,12 @@ def main():
             "pairs": int(st["pairs"]), "passes_max": int(st["passes_max"]),
             "walk_ms": float(np.mean(timers["walk"])) if timers["walk"] else 0.0,
             "bucket_ms": float(np.mean(timers["bucket"])) if timers["bucket"] else 0.0,
-            "copy_ms": float(np.mean(timers["copy"])) if timers["copy"] else 0.0, "digests": digests}
+            "copy_ms": float(np.mean(timers["copy"])) if timers["copy"] else 0.0, "digests": digests,
+            "step_ms": [float(np.min(timers["step"])), float(np.median(timers["step"])), float(np.max(timers["step"]))]
+            if timers["step"] else None,
+            "walk_ms_mmm": [float(np.min(timers["walk"])), float(np.median(timers["walk"])), float(np.max(timers["walk"]))]
+            if timers["walk"] else None,
+            "path": timers.get("path")}
     parts = [part]
     if dist is not None:
         parts = [None] * world
@@ -640,9 +756,21 @@ def main():
             "value": matched_step * args.steps / elapsed_max,
             "unit": "matched players/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
+            "launched_by": "bench.py itself (--gpus N without a launcher)" if os.environ.get("MM_BENCH_LAUNCHED") else
+                           ("torch.distributed.run / env" if world > 1 else "single process"),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": step_ms,
+            # the K timed steps one by one (host clock; the slowest rank's): what the mean above hides — runs of this line on
+            # one box have differed by 8 %, so a reader can tell a regression from the box
+            "ms_per_step_min_median_max": slow["step_ms"],
+            "walk_ms_min_median_max": slow["walk_ms_mmm"],
+            # which launch shapes the last timed tick of the slowest rank took (mm_path_stats_get) — `degraded`: a fall-back was in
+            # force (a kp_rounds stop or its cool-down, kp_rounds off, kt_fc chunk flags that did not come): results identical,
+            # the timing not the headline path's
+            "path": slow["path"],
+            "degraded": bool(any((p.get("path") or {}).get("degraded") for p in parts)),
             "higher_is_better": True,
             "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
@@ -679,7 +807,7 @@ def main():
             "roofline": None,
         }
         main_roofline_args = (args.mode, pairs, wl["bytes_per_pair"], slow["walk_ms"], step_ms, n,
-                              max(p["passes_max"] for p in parts), traffic, tnote, tdet)
+                              max(p["passes_max"] for p in parts), traffic, tnote, tdet, slow["path"])
         if world == 1 and not args.no_cpu_baseline:
             cfg_cpu = make_config(wl["modes"], capacity=pow2(n), device=local_rank, timing=False)
             line["cpu_baseline"] = cpu_baseline(cfg_cpu, rating, cons, args.mode, budget_s=args.cpu_baseline_seconds)
@@ -830,10 +958,10 @@ def main():
     if rank == 0:
         boundary_us = None if args.no_boundary else measure_boundary_us(torch)
         a = main_roofline_args
-        line["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9] if len(a) > 9 else None)
+        line["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9], a[10])
         if "cfg3" in line and "_roofline_args" in line["cfg3"]:
             a = line["cfg3"].pop("_roofline_args")
-            line["cfg3"]["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9] if len(a) > 9 else None)
+            line["cfg3"]["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9], a[10])
         for leg in ("shared_pool_n1",):
             if leg in line:
                 line[leg].pop("_roofline_args", None)

@@ -272,6 +272,54 @@ int mm_snapshot_size(mm_engine* e, uint64_t* bytes);
 int mm_snapshot(mm_engine* e, void* buf, uint64_t cap, uint64_t* written);
 int mm_restore(mm_engine* e, const void* buf, uint64_t bytes);
 
+/* ---- which launch shapes the last tick took, and the fall-backs it met ------------
+ * The walk has persistent launch shapes (several passes per launch) that depend on behaviour the hardware is
+ * observed, not promised, to have; when an observation fails the engine falls back to one launch per pass —
+ * results identical, the tick slower.  The reference has no counterpart (its worker is one process,
+ * search/worker.ex:291-324); an operator of THIS engine needs to tell a regression from a fall-back, and
+ * mm_stats is frozen (ABI version 1), hence a separate, size-versioned record: the caller sets `size` to its
+ * sizeof(mm_path_stats), the engine fills at most that many bytes and stores what it filled.  Diagnostics
+ * only — never control flow, never results. */
+#define MM_PATH_GENERIC 1u /* k_walk took chains                                       */
+#define MM_PATH_PAIR    2u /* the pair path (1v1 modes)                                 */
+#define MM_PATH_TEAM    4u /* the team path                                             */
+typedef struct mm_path_stats {
+    uint32_t size;                 /* in: sizeof(mm_path_stats) of the caller; out: bytes filled */
+    uint32_t mode;                 /* the mode of the last mm_tick (0xFFFFFFFF: no tick yet)     */
+    uint32_t paths;                /* MM_PATH_* of the last tick                                  */
+    uint32_t host_looks;           /* synchronous looks of the host at the chains in that tick    */
+    /* pair path */
+    uint32_t pair_rounds_launches; /* launches of several passes each (kp_rounds)                 */
+    uint32_t pair_rounds_passes;   /* passes of the longest chain walked inside them              */
+    uint32_t pair_round_launches;  /* launches of one pass each (kp_round)                        */
+    uint32_t pair_tiled_passes;    /* passes of the longest chain on the tiled path, both kinds   */
+    uint32_t pair_stops_timeout;   /* kp_rounds launches that gave up in that tick: a barrier waited too long */
+    uint32_t pair_stops_xcd;       /* ... a chain's workgroups were not on one XCD                */
+    uint32_t pair_stops_inject;    /* ... the test hook                                           */
+    uint32_t pair_yields;          /* batches ended early for a compaction (no fall-back)         */
+    uint32_t pair_persist_off;     /* 1: kp_rounds is off in this engine for good (two XCDs seen, or MM_PAIR_PERSIST=0) */
+    uint32_t pair_cooldown;        /* batches for which kp_rounds still stays off after a stop    */
+    uint32_t pair_stops_total;     /* stops since mm_engine_create                                */
+    /* team path */
+    uint32_t team_f_launches;      /* kt_f (+ kt_f2 + kt_chase) passes                            */
+    uint32_t team_fc_launches;     /* kt_fc passes (kt_f, chase and emission in one launch)       */
+    uint32_t team_late_launches;   /* kt_late launches (the last passes back to back)             */
+    uint32_t team_build_launches;  /* kt_build launches                                           */
+    uint32_t team_flags_late;      /* kt_fc: anchors whose chunk flag did not come in time in that tick (the chaser looked the lobby up itself) */
+    uint32_t team_flags_late_total;/* ... since mm_engine_create                                  */
+    /* the chain with the most passes of that tick (the tick's critical path), pair path */
+    uint32_t crit_group;           /* its rating group                                            */
+    uint32_t crit_passes;          /* its passes                                                  */
+    uint32_t crit_rounds_passes;   /* ... of them inside kp_rounds launches                       */
+    uint32_t crit_rounds_hops;     /* ... dependent route hops its walks took there (tile 1's walker counts them) */
+    uint32_t crit_round_passes;    /* ... of them as kp_round launches                            */
+    uint32_t crit_late_passes;     /* ... of them inside kp_late                                  */
+    uint32_t crit_late_lobbies;    /* lobbies it emitted inside kp_late (one dependent LDS step each) */
+    uint32_t degraded;             /* 1: a fall-back was in force during that tick (a stop, the cool-down, kp_rounds off, late flags):
+                                         its timing is not the headline path's                    */
+} mm_path_stats;
+int mm_path_stats_get(mm_engine* e, mm_path_stats* out);
+
 /* Last HIP error code seen by this engine (0 if none) — for logs, never for control flow. */
 int mm_last_hip_error(const mm_engine* e);
 

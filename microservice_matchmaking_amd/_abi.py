@@ -73,6 +73,22 @@ class MMEnqueueStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class MMPathStats(C.Structure):
+    """include/mm_engine.h mm_path_stats: the launch shapes and fall-backs of the last tick (size-versioned)."""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "size", "mode", "paths", "host_looks",
+        "pair_rounds_launches", "pair_rounds_passes", "pair_round_launches", "pair_tiled_passes",
+        "pair_stops_timeout", "pair_stops_xcd", "pair_stops_inject", "pair_yields",
+        "pair_persist_off", "pair_cooldown", "pair_stops_total",
+        "team_f_launches", "team_fc_launches", "team_late_launches", "team_build_launches",
+        "team_flags_late", "team_flags_late_total",
+        "crit_group", "crit_passes", "crit_rounds_passes", "crit_rounds_hops", "crit_round_passes", "crit_late_passes",
+        "crit_late_lobbies", "degraded")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "size"}
+
+
 class MMError(RuntimeError):
     def __init__(self, status, where):
         self.status = int(status)
@@ -92,7 +108,7 @@ ABI_FUNCTIONS = [
     "tick", "matches", "queue_depth", "queue_slots", "lobby_state",
 ]
 PRODUCT_ONLY_FUNCTIONS = ["abi_version", "strerror", "config_default", "enqueue_device",
-                          "last_hip_error"]
+                          "last_hip_error", "path_stats_get"]
 
 
 class MMCodecCfg(C.Structure):
@@ -253,6 +269,18 @@ class EngineBase:
 
     def reset(self):
         self._check(self._fn("reset")(self._h), "reset")
+
+    def path_stats(self):
+        """mm_path_stats_get as a dict, or None for a library without it (the oracle: it has one way to walk)."""
+        fn = getattr(self._lib, self._prefix + "path_stats_get", None)
+        if fn is None:
+            return None
+        fn.argtypes = [C.c_void_p, C.POINTER(MMPathStats)]
+        fn.restype = C.c_int
+        ps = MMPathStats()
+        ps.size = C.sizeof(MMPathStats)
+        self._check(fn(self._h, C.byref(ps)), "path_stats_get")
+        return ps.as_dict()
 
     def find_rating_group(self, rating):
         g = C.c_uint32()

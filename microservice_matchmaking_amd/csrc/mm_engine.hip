@@ -958,6 +958,9 @@ struct mm_engine {
     bool pair_xcd;             // MM_PAIR_XCD=0: kp_round on the plain (tile, group) grid (A/B)
     uint32_t pair_group_min;   // MM_PAIR_GROUP: tiles of the longest chain from which a batch runs with the second level (0 = never)
     PairChain* h_pchains;      // pinned
+    uint32_t ps_hand[4][MM_MAX_GROUPS];   // per rating group at the pair path's last look: passes, lobbies, kp_rounds passes, kp_rounds hops
+    mm_path_stats ps;          // mm_path_stats_get: the launch shapes and fall-backs of the last tick (totals carried over)
+    uint32_t team_fwait, team_fix_max, team_fix_t8, team_fix_t4, team_pull_xcd, team_nowait;   // MM_TEAM_* knobs of kt_f / kt_fc, read once at create
     uint32_t pk_bits_stride, pk_max_tiles, pk_stride;
     uint32_t pair_batch;       // MM_PAIR_BATCH: tiled rounds launched per host look at the chains
     bool force_generic;        // MM_FORCE_GENERIC=1: always walk with k_walk (A/B testing)
@@ -1364,8 +1367,10 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* pto = getenv("MM_PAIR_PTIMEOUT_US");
             // the first barrier of a launch is where a workgroup that found no CU is waited for (another engine's launch in the
             // way ends within a millisecond or two); behind it everybody is on the chip and only slow, never absent
-            e->pair_ptimeout[0] = (pto ? (uint32_t)strtoul(pto, NULL, 0) : 20000u) * 100u;
-            e->pair_ptimeout[1] = e->pair_ptimeout[0] * 10u;
+            // — 5 ms, half a tick period of the stream (20 ms until round 5: two whole periods of spinning whenever somebody
+            // else held the CUs, and kp_round is a cheap way on); 200 ms behind it, as before
+            e->pair_ptimeout[0] = (pto ? (uint32_t)strtoul(pto, NULL, 0) : 5000u) * 100u;
+            e->pair_ptimeout[1] = e->pair_ptimeout[0] * 40u;
             e->pair_pcool = 0;
             e->pair_pstops = 0;
             const char* ppb = getenv("MM_PAIR_PBATCH");
@@ -1386,6 +1391,22 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             const char* tem = getenv("MM_TEAM_EMIT_MAX");
             e->team_emit_max = tem ? (uint32_t)strtoul(tem, NULL, 0) : TC_EMIT_MAX;   // emitter workgroups per chain and launch at most
             { const char* tsp = getenv("MM_TEAM_SPLIT"); e->team_split = tsp ? (uint32_t)strtoul(tsp, NULL, 0) : 1u; }
+            {   // (read here, once: getenv on the tick's path is neither cheap nor safe beside a setenv of the host process)
+                const char* fw = getenv("MM_TEAM_FWAIT");
+                e->team_fwait = fw ? (uint32_t)strtoul(fw, NULL, 0) : (1u << 14);       // ~5 ms of polls, then the chaser helps itself
+                const char* fm = getenv("MM_TEAM_FIXMAX");
+                e->team_fix_max = fm ? (uint32_t)strtoul(fm, NULL, 0) : 0xFFFFFFFFu;   // (measured: mending always wins once a task is a quarter wave's)
+                const char* f8 = getenv("MM_TEAM_FIXT8");
+                const char* f4 = getenv("MM_TEAM_FIXT4");
+                e->team_fix_t8 = f8 ? (uint32_t)strtoul(f8, NULL, 0) : 10u;
+                e->team_fix_t4 = f4 ? (uint32_t)strtoul(f4, NULL, 0) : 64u;
+                const char* px = getenv("MM_TEAM_PULLX");
+                e->team_pull_xcd = px ? (uint32_t)strtoul(px, NULL, 0) : 1u;
+                const char* nw = getenv("MM_TEAM_NOWAIT");
+                e->team_nowait = nw ? (uint32_t)strtoul(nw, NULL, 0) : 0u;
+                memset(&e->ps, 0, sizeof(e->ps));
+                e->ps.mode = 0xFFFFFFFFu;
+            }
             if (e->team_emit_max < 1u) e->team_emit_max = 1u;
             const char* tlv = getenv("MM_TEAM_LIVE");
             e->team_live = !(tlv && tlv[0] == '0');                      // 0: kt_f and kt_chase as launches of their own in every pass (cfg-3: +0.7 ms per tick)
@@ -1963,16 +1984,21 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     HIPCHK(e, hipGetLastError());
     uint32_t tail_no[MM_MAX_GROUPS];
     bool tail_send = false;
+    memset(e->ps_hand, 0, sizeof(e->ps_hand));
     // ---- tiled rounds for the chains that do not fit one workgroup's LDS ----
     if (bound >= PL_MAX) {
         uint32_t tiles = (bound + PK_T - 1u) / PK_T + 1u;
         if (tiles > e->pk_max_tiles) tiles = e->pk_max_tiles;
+        bool after_persist = false;            // the look directly behind a kp_rounds launch: only there is PairChain.pfail news
         for (uint32_t guard = 0;; ++guard) {
-            // every batch retires at least one pass of every tiled chain, a pass without a change
-            // ends the chain: capacity passes are an upper bound (never reached in practice)
-            if (guard > cfg.capacity / e->pair_batch + 64u) return MM_ERR_INTERNAL;
+            // A pass without a change ends a chain, so a chain has at most `capacity` passes; an iteration retires at least one
+            // pass of every tiled chain, or is one of the few kinds that retire none and are each followed by one that does
+            // (a compaction-only look; a kp_rounds launch that stopped at its first barrier, after which kp_rounds stays off
+            // for 16 batches): three iterations per pass are an upper bound (never reached in practice)
+            if (guard > 3u * cfg.capacity + 64u) return MM_ERR_INTERNAL;
             HIPCHK(e, hipMemcpyAsync(e->h_pchains, e->d_pchains, G * sizeof(PairChain), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(e, hipStreamSynchronize(e->stream));
+            ++e->ps.host_looks;
             bool tiled = false, compact = false;
             uint32_t longest = 0;
             for (uint32_t g = 0; g < G; ++g) {
@@ -1980,12 +2006,20 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 P.bm[g] = 0;
                 P.bbuf[g] = 0;
                 if (!pc.fast || pc.stage != PS_TILED) continue;
-                if (pc.pfail && (pc.pfail & 0xFFu) != PF_YIELD) {
+                // (pfail is written by kp_init and by kp_rounds' epilogue only and stays in the record: it is looked at once,
+                // at the look directly behind the launch that wrote it — a later look of the tick would count the same stop again
+                // and start the cool-down anew)
+                if (after_persist && pc.pfail && (pc.pfail & 0xFFu) == PF_YIELD) ++e->ps.pair_yields;
+                if (after_persist && pc.pfail && (pc.pfail & 0xFFu) != PF_YIELD) {
                     // the last kp_rounds launch gave up on this chain (its state is committed): one launch per pass for a while.
                     // A chain that found itself on two XCDs says the dispatch is not what the map assumes: never again.
                     ++e->pair_pstops;
                     e->pair_pcool = 16u;
-                    if ((pc.pfail & 0xFFu) == PF_XCD) e->pair_persist = false;
+                    const uint32_t why = pc.pfail & 0xFFu;
+                    if (why == PF_XCD) { e->pair_persist = false; ++e->ps.pair_stops_xcd; }
+                    else if (why == PF_INJECT) ++e->ps.pair_stops_inject;
+                    else ++e->ps.pair_stops_timeout;
+                    e->ps.degraded = 1;
                     if (e->pair_debug) fprintf(stderr, "[mm-pair] g%u: kp_rounds stopped (reason %u, iteration %u)\n", g, pc.pfail & 0xFFu, pc.pfail >> 8);
                 }
                 P.bm[g] = pc.m;                       // constant until the next compaction, i.e. for the whole batch
@@ -2001,6 +2035,20 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 uint32_t bf[MM_MAX_GROUPS];
                 for (uint32_t g = 0; g < G; ++g) { bf[g] = e->h_pchains[g].before; sent_no[g] = e->h_pchains[g].fast ? e->h_pchains[g].n_out : 0u; }
                 if (!e->r_based) results_set_bases(e, bf, M.L);
+            }
+            after_persist = false;
+            for (uint32_t g = 0; g < G; ++g) {
+                const PairChain& pc = e->h_pchains[g];
+                if (!pc.fast) continue;
+                if (pc.ppass > e->ps.pair_rounds_passes) e->ps.pair_rounds_passes = pc.ppass;
+                if (pc.rounds > e->ps.pair_tiled_passes) e->ps.pair_tiled_passes = pc.rounds;
+            }
+            for (uint32_t g = 0; g < G; ++g) {         // (what the tiled path had done when kp_late took over: the last look's is kept)
+                const PairChain& pc = e->h_pchains[g];
+                e->ps_hand[0][g] = pc.fast ? pc.passes : 0u;
+                e->ps_hand[1][g] = pc.fast ? pc.n_out : 0u;
+                e->ps_hand[2][g] = pc.fast ? pc.ppass : 0u;
+                e->ps_hand[3][g] = pc.fast ? pc.ptm[15] : 0u;
             }
             if (!tiled) {
                 // the chains' LDS-resident ends (kp_late) run next: what the tiled rounds have emitted since the last look leaves
@@ -2039,7 +2087,9 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             uint32_t tp = PK_TMAX;
             // several passes per launch (kp_rounds) when every chain's tiles fit the CUs of one XCD
             bool persist = e->pair_fused && e->pair_persist && !compact && (longest + PK_TMAX - 1u) / PK_TMAX <= e->pair_ptiles;
-            if (persist && e->pair_pcool) { --e->pair_pcool; persist = false; }
+            if (persist && e->pair_pcool) { --e->pair_pcool; persist = false; e->ps.degraded = 1; }
+            // (a batch that kp_rounds would have taken, walked launch by launch because it is off: a fall-back's timing)
+            if (e->pair_fused && !e->pair_persist && !compact && (longest + PK_TMAX - 1u) / PK_TMAX <= e->pair_ptiles) e->ps.degraded = 1;
             const uint32_t tiles_max = persist && e->pair_ptiles < e->pair_tiles_max ? e->pair_ptiles : e->pair_tiles_max;
             if (e->pair_fused && !e->pair_tile_fixed)
                 for (uint32_t cand = PK_TMAX / 4u; cand < PK_TMAX; cand <<= 1)    // (an eighth was measured: slower, the fixed cost of a round takes over)
@@ -2089,6 +2139,8 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                         const uint32_t K = e->pair_pbatch, slice = MM_PERSIST_SLICE ? MM_PERSIST_SLICE : K + 1u;
                         for (uint32_t it = 0; it <= K; it += slice)
                             TILE_LAUNCH(kp_rounds, dim3(8u * slots), dim3(PT_THREADS), P, it, it + slice < K + 1u ? it + slice : K + 1u, K);
+                        ++e->ps.pair_rounds_launches;
+                        after_persist = true;
                         COMPACT_LAUNCH();
                         HIPCHK(e, hipGetLastError());
                         { int arc = results_absorb(e, M.L); if (arc) return arc; }
@@ -2107,6 +2159,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 if (P.grp) TILE_LAUNCH(kp_group, dim3(ngr, G), dim3(1024), P, r);
                 for (uint32_t b = 0; b < (want_fit && e->pair_batch > 12u ? 12u : e->pair_batch); ++b) {
                     TILE_LAUNCH(kp_round, rgrid, dim3(PT_THREADS), P, r, 0u);
+                    ++e->ps.pair_round_launches;
                     ++r;
                     if (P.grp) TILE_LAUNCH(kp_group, dim3(ngr, G), dim3(1024), P, r);
                 }
@@ -2167,20 +2220,12 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     P.n_released = e->d_counters;
     P.scan_cap = e->team_cap;
     P.late_bail = 4u * e->team_late + 32u;
-    {
-        const char* fw = getenv("MM_TEAM_FWAIT");
-        P.fwait = fw ? (uint32_t)strtoul(fw, NULL, 0) : (1u << 14);       // ~5 ms of polls, then the chaser helps itself
-        const char* fm = getenv("MM_TEAM_FIXMAX");
-        P.fix_max = fm ? (uint32_t)strtoul(fm, NULL, 0) : 0xFFFFFFFFu;   // (measured: mending always wins once a task is a quarter wave's)
-        const char* f8 = getenv("MM_TEAM_FIXT8");
-        const char* f4 = getenv("MM_TEAM_FIXT4");
-        P.fix_t8 = f8 ? (uint32_t)strtoul(f8, NULL, 0) : 10u;
-        P.fix_t4 = f4 ? (uint32_t)strtoul(f4, NULL, 0) : 64u;
-        const char* px = getenv("MM_TEAM_PULLX");
-        P.pull_xcd = px ? (uint32_t)strtoul(px, NULL, 0) : 1u;
-        const char* nw = getenv("MM_TEAM_NOWAIT");
-        P.nowait = nw ? (uint32_t)strtoul(nw, NULL, 0) : 0u;
-    }
+    P.fwait = e->team_fwait;
+    P.fix_max = e->team_fix_max;
+    P.fix_t8 = e->team_fix_t8;
+    P.fix_t4 = e->team_fix_t4;
+    P.pull_xcd = e->team_pull_xcd;
+    P.nowait = e->team_nowait;
     P.debug = e->pair_debug ? (e->team_batch == 1u ? 3u : 1u) : 0u;   // bit 1 (with MM_TEAM_BATCH=1): kt_f counts every F it writes — an atomic per thread
     P.seq = 0;
     P.n_emit = 0;
@@ -2274,12 +2319,14 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
     uint32_t team_no[MM_MAX_GROUPS];
     bool team_have = false, force_build = false;
     bool late_now = late_ok && e->team_late0 != 0u && arrivals <= e->team_late0;
-    if (late_now) hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+    ++e->ps.host_looks;
+    if (late_now) { hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P); ++e->ps.team_build_launches; }
     for (uint32_t guard = 0;; ++guard) {
         // a pass that changes nothing ends a chain and every other pass seats somebody
         if (guard > cfg.capacity + 64u) return MM_ERR_INTERNAL;
         if (late_now) {
             hipLaunchKernelGGL(kt_late, dim3(G), dim3(TL_THREADS), 0, e->stream, P);
+            ++e->ps.team_late_launches;
             force_build = true;                       // whoever comes back from kt_late needs fresh sub-queues
         } else {
             for (uint32_t b = 0; b < batch; ++b, ++pass) {
@@ -2287,8 +2334,10 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
                 P.use_f2 = pass < e->team_f2 ? 1u : 0u;
                 // the role sub-queues are rebuilt in the first two passes (a head that sat out the first one is back in
                 // the second) and every team_rebuild passes after; in between, players that leave are tombstones in them
-                if (pass < 2u || pass % e->team_rebuild == 0u || force_build)
+                if (pass < 2u || pass % e->team_rebuild == 0u || force_build) {
                     hipLaunchKernelGGL(kt_build, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
+                    ++e->ps.team_build_launches;
+                }
                 force_build = false;
                 // the emitters ride in the chase's launch, enough waves for the lobbies the last look saw per pass (a pass
                 // that emits more than that is only slower); MM_TEAM_FUSED=0: kt_emit as a launch of its own behind it
@@ -2302,12 +2351,15 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
                     hipLaunchKernelGGL(kt_f, dim3(nch + (e->team_split ? 1u : 0u), G), dim3(TT_CH), 0, e->stream, P);
                     hipLaunchKernelGGL(kt_f2, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
                     hipLaunchKernelGGL(kt_chase<1>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
+                    ++e->ps.team_f_launches;
                 } else if (e->team_live) {
+                    ++e->ps.team_fc_launches;
                     // kt_f and the chase of the pass in one launch: the chasers take F chunk by chunk as it is written
                     hipLaunchKernelGGL(kt_fc, dim3(G * (1u + P.n_emit) + fo_total), dim3(TT_CH), 0, e->stream, P);
                 } else {
                     hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
                     hipLaunchKernelGGL(kt_chase<0>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
+                    ++e->ps.team_f_launches;
                 }
                 if (!e->team_fused) hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
             }
@@ -2320,6 +2372,12 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         { int arc = results_absorb(e, M.L); if (arc) return arc; }
         if (team_have) { int src = results_send(e, team_no, M.L, e->results_early ? MM_RESULTS_MIN_TEAM : 0xFFFFFFFFu); if (src) return src; }
         HIPCHK(e, hipStreamSynchronize(e->stream));
+        ++e->ps.host_looks;
+        {   // kt_fc's chasers count the anchors whose chunk flag did not come (they looked the lobby up themselves)
+            uint32_t fl = 0;
+            for (uint32_t g = 0; g < G; ++g) if (e->h_tchains[g].fast) fl += e->h_tchains[g].flags_late;
+            e->ps.team_flags_late = fl;
+        }
         bool busy = false, late = late_ok;
         uint32_t most = 0;
         for (uint32_t g = 0; g < G; ++g) {
@@ -2373,6 +2431,7 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         // close to the switch: look again soon (a look costs a D2H round trip, an idle pass a launch)
         batch = (e->team_late && most <= 3u * e->team_late) ? (e->team_batch < 4u ? e->team_batch : 4u) : e->team_batch;
     }
+    if (e->ps.team_flags_late) { e->ps.team_flags_late_total += e->ps.team_flags_late; e->ps.degraded = 1; }
     hipLaunchKernelGGL(kt_fin_scatter, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
     hipLaunchKernelGGL(kt_fin_copy, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
@@ -2439,6 +2498,12 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     const bool purge = e->cancel_pending > 0;
     e->r_n = 0;
     e->r_L = M.L;
+    {   // mm_path_stats_get: this tick's record (the totals go on)
+        const uint32_t tot = e->ps.team_flags_late_total;
+        memset(&e->ps, 0, sizeof(e->ps));
+        e->ps.mode = mode;
+        e->ps.team_flags_late_total = tot;
+    }
     if (e->ev_copy_pending) { (void)hipEventSynchronize(e->ev_copy); e->ev_copy_pending = false; }   // (a tick that failed half way)
     e->r_based = false;
     for (uint32_t g = 0; g < G; ++g) { e->r_sent[g] = 0; e->r_marked[g] = 0; e->r_cnt[g] = 0; }
@@ -2454,6 +2519,7 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     const bool use_pair = M.team_size == 1u && M.teams == 2u && !e->force_generic;
     if (use_pair) {
         RoctxRange rr("mm_tick/pair walk");
+        e->ps.paths |= MM_PATH_PAIR;
         int prc = pair_walk(e, mode, M, purge);
         if (prc) return prc;
     }
@@ -2463,6 +2529,10 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
         RoctxRange rr("mm_tick/team walk");
         int trc = team_walk(e, mode, M, purge, &team_any);
         if (trc) return trc;
+        if (team_any) e->ps.paths |= MM_PATH_TEAM;
+    }
+    if (!e->ps.paths) e->ps.paths = MM_PATH_GENERIC;        // (k_walk also takes the short chains the other two leave: not recorded)
+    {
     }
     WalkParams P;
     memset(&P, 0, sizeof(P));
@@ -2619,6 +2689,19 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     }
     e->r_n = total;
     if (n_matches) *n_matches = total;
+    if (e->ps.paths & MM_PATH_PAIR) {            // mm_path_stats_get: the chain with the most passes, by launch shape
+        uint32_t gc = 0;
+        for (uint32_t g = 1; g < G; ++g)
+            if (e->h_chains[mode * G + g].passes > e->h_chains[mode * G + gc].passes) gc = g;
+        const ChainDev& cd = e->h_chains[mode * G + gc];
+        e->ps.crit_group = gc;
+        e->ps.crit_passes = cd.passes;
+        e->ps.crit_rounds_passes = e->ps_hand[2][gc];
+        e->ps.crit_rounds_hops = e->ps_hand[3][gc];
+        e->ps.crit_round_passes = e->ps_hand[0][gc] >= e->ps_hand[2][gc] ? e->ps_hand[0][gc] - e->ps_hand[2][gc] : 0u;
+        e->ps.crit_late_passes = cd.passes >= e->ps_hand[0][gc] ? cd.passes - e->ps_hand[0][gc] : 0u;
+        e->ps.crit_late_lobbies = cd.n_out >= e->ps_hand[1][gc] ? cd.n_out - e->ps_hand[1][gc] : 0u;
+    }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->pool_before = before;
@@ -2909,5 +2992,19 @@ extern "C" int mm_restore(mm_engine* e, const void* buf, uint64_t bytes)
 }
 
 extern "C" int mm_last_hip_error(const mm_engine* e) { return e ? e->last_hip : 0; }
+
+// include/mm_engine.h: the launch shapes and fall-backs of the last tick.  Host state only — no device call.
+extern "C" int mm_path_stats_get(mm_engine* e, mm_path_stats* out)
+{
+    if (!e || !out || out->size < 2u * sizeof(uint32_t)) return MM_ERR_INVALID_ARG;
+    mm_path_stats ps = e->ps;
+    ps.pair_persist_off = e->pair_persist ? 0u : 1u;
+    ps.pair_cooldown = e->pair_pcool;
+    ps.pair_stops_total = e->pair_pstops;
+    const uint32_t n = out->size < (uint32_t)sizeof(ps) ? out->size : (uint32_t)sizeof(ps);
+    ps.size = n;
+    memcpy(out, &ps, n);
+    return MM_OK;
+}
 
 #include "mm_codec.inc"

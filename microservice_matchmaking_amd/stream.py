@@ -48,7 +48,11 @@ def stream_schedule(qps, seconds, tick_ms, seed):
 def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=True, batches=None):
     """Drive `search` (a sharding.ShardedSearch: one engine + the chains this rank owns) through
     the schedule.  Returns a dict with per-mode latency arrays (real, floor), matched players,
-    per-tick cost and a digest per chain of everything it emitted, in order."""
+    per-tick cost and a digest per chain of everything it emitted, in order.
+    `batches`: the arrivals of every tick of the schedule, made by the caller before the clock starts
+    (stream_batch(n, seed, ...) per entry — at 200 000 players a tick numpy needs longer than the 10 ms period to
+    draw them, and a leg would fall behind because of the host, not the engine)."""
+    assert batches is None or len(batches) == len(schedule)
     cfg = search.cfg
     n_modes, n_groups = int(cfg.n_modes), int(cfg.n_groups)
     total = sum(s[2] for s in schedule)
@@ -69,8 +73,8 @@ def run_stream(search, schedule, mode_weights=None, role_weights=None, realtime=
         gc.disable()
     t_start = time.perf_counter()
     try:
-        for (t_open, t_close, n, sd, ts) in schedule:
-            rating, cons = stream_batch(n, sd, mode_weights, role_weights)
+        for k, (t_open, t_close, n, sd, ts) in enumerate(schedule):
+            rating, cons = batches[k] if batches is not None else stream_batch(n, sd, mode_weights, role_weights)
             arrival[first:first + n] = ts
             if realtime:
                 # the period has to be over: sleep through most of it and spin only for the last stretch (a thread that spins

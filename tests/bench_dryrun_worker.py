@@ -17,6 +17,7 @@ from test_bench_line import DryEngine  # noqa: E402
 
 torch.cuda.is_available = lambda: True
 torch.cuda.set_device = lambda d: None
+torch.cuda.device_count = lambda: 8
 torch.cuda.synchronize = lambda *a: None
 torch.Tensor.cuda = lambda self, *a, **k: self
 _tensor = torch.tensor
@@ -27,6 +28,11 @@ pkg.Engine = DryEngine
 
 import bench  # noqa: E402
 
+# `bench.py --gpus N` without a launcher re-executes itself once per rank: in the dry run, this worker
+bench.SELF_CMD = [sys.executable, os.path.abspath(__file__)]
+
 if __name__ == "__main__":
     sys.argv = ["bench.py"] + sys.argv[1:]
+    if "LOCAL_RANK" in os.environ:
+        os.environ["LOCAL_RANK"] = "0"               # the shim has one device
     bench.main()

@@ -9,7 +9,7 @@ import pytest
 
 from conftest import ROOT
 from microservice_matchmaking_amd import MMError, make_config, mode_1v1
-from microservice_matchmaking_amd._abi import MMConfig, MMEnqueueStats, MMModeConfig, MMStats
+from microservice_matchmaking_amd._abi import MMConfig, MMEnqueueStats, MMModeConfig, MMPathStats, MMStats
 from microservice_matchmaking_amd.engine import LIB_PATH, load_library
 
 HEADERS = [os.path.join(ROOT, "include", h) for h in ("mm_engine.h", "mm_codec.h")]
@@ -42,7 +42,7 @@ def test_oracle_exports_the_mirrored_abi(oracle_cls):
     olib = load()
     for n in declared_functions():
         if n in ("mm_abi_version", "mm_strerror", "mm_config_default", "mm_enqueue_device",
-                 "mm_last_hip_error", "mm_snapshot_size", "mm_snapshot", "mm_restore", "mm_decode_players", "mm_encode_lobby"):
+                 "mm_last_hip_error", "mm_path_stats_get", "mm_snapshot_size", "mm_snapshot", "mm_restore", "mm_decode_players", "mm_encode_lobby"):
             continue
         assert hasattr(olib, "mo_" + n[3:]), n
 
@@ -52,13 +52,13 @@ def test_struct_layouts_match_the_header(lib):
     probe = r'''
 #include <stdio.h>
 #include "mm_engine.h"
-int main(void){printf("%zu %zu %zu %zu\n", sizeof(mm_config), sizeof(mm_mode_config), sizeof(mm_stats), sizeof(mm_enqueue_stats));return 0;}
+int main(void){printf("%zu %zu %zu %zu %zu\n", sizeof(mm_config), sizeof(mm_mode_config), sizeof(mm_stats), sizeof(mm_enqueue_stats), sizeof(mm_path_stats));return 0;}
 '''
     exe = "/tmp/mm_abi_probe"
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe],
                    input=probe.encode(), check=True)
     sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [C.sizeof(MMConfig), C.sizeof(MMModeConfig), C.sizeof(MMStats), C.sizeof(MMEnqueueStats)]
+    assert sizes == [C.sizeof(MMConfig), C.sizeof(MMModeConfig), C.sizeof(MMStats), C.sizeof(MMEnqueueStats), C.sizeof(MMPathStats)]
 
 
 def test_library_level_calls_need_no_gpu(lib):

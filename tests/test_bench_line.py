@@ -44,6 +44,21 @@ def test_roofline_block_reproduces_the_committed_line():
     assert lat["us_per_pass"] == pytest.approx(16000.0 / 600) and lat["traffic_note"] == "stale"
 
 
+def test_critical_path_model_is_barriers_hops_boundaries_and_lds_steps():
+    # the driver's cfg-2 tick of round 4: 336 passes in kp_rounds with 24 hops each, 26 kp_round launches, 270 passes in kp_late
+    path = {"paths": 2, "crit_group": 0, "crit_passes": 632, "crit_rounds_passes": 336, "crit_rounds_hops": 336 * 24,
+            "crit_round_passes": 26, "crit_late_passes": 270, "crit_late_lobbies": 7300}
+    ms, parts = bench.critical_path_ms(path, boundary_us=2.0)
+    c = bench.CRIT
+    assert parts["kp_rounds"] == pytest.approx((336 * c["barrier_us"] + 336 * 24 * c["hop_l2_us"]) * 1e-3)
+    assert parts["kp_round"] == pytest.approx(26 * (2.0 + 24 * c["hop_mem_us"]) * 1e-3)
+    assert parts["kp_late"] == pytest.approx((7300 * c["late_step_us"] + 270 * c["late_pass_us"]) * 1e-3)
+    assert ms == pytest.approx(sum(parts.values())) and 1.5 < ms < 2.5
+    r = bench.roofline_block("1v1", 7e7, 8, 9.6, 10.3, 1_000_000, 632, None, 2.0, None, None, path)
+    assert r["frac_of_critical_path"] == pytest.approx(ms / 9.6) and r["latency_floor_ms"] == pytest.approx(632 * 2.0e-3)
+    assert bench.critical_path_ms(None) == (None, None) and bench.critical_path_ms({"paths": 4, "crit_passes": 9}) == (None, None)
+
+
 def test_predict_speedup_is_the_slowest_rank_not_the_load_share():
     # BASELINE cfg-4 as measured on one GPU in round 2: the pool 66.8 ms, its 3M-player chain alone ~55 ms
     assert bench.predict_speedup(66.8, [55.0, 20.0, 0.0, 18.0]) == pytest.approx(66.8 / 55.0)
@@ -132,6 +147,16 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
     assert r["traffic"] is None and "traffic_note" in r   # the PMC figure belongs to the 1M-player workload only
     ex = d["exactness"]                              # the emission digest against the oracle's (committed) digest
     assert ex["ok"] is True and ex["emission_digest"] == ex["oracle_digest"] and ex["key"].startswith(mode + "/12000/")
+    # the launch shapes / fall-backs of the last timed tick (mm_path_stats_get), the spread of the timed steps
+    assert d["degraded"] is False and d["path"]["paths"] == (2 if mode == "1v1" else 1) and d["path"]["host_looks"] >= 0
+    lo, med, hi = d["ms_per_step_min_median_max"]
+    assert lo <= med <= hi and lo <= d["ms_per_step"] * 1.0001 and d["n_gpus"] == d["rccl_ranks"] == 1
+    if mode == "1v1":                                # 12000 players: every chain is kp_late's from its first pass
+        assert r["critical_path_ms"] > 0 and r["critical_path_model"]["passes"]["kp_rounds"] == 0
+        assert r["critical_path_model"]["passes"]["kp_late"] == d["path"]["crit_passes"] == d["passes_max"]
+    else:
+        # (3 600 players in the longest chain: below the team path's 4 096, k_walk takes every chain of the dry run's pool)
+        assert r["critical_path_ms"] is None and d["path"]["team_f_launches"] + d["path"]["team_fc_launches"] == 0
     assert d["pcie_inclusive"]["value"] > 0 and d["pcie_inclusive"]["steps"] == 2      # the pool handed over in host buffers
     sp = d["shared_pool_n1"]                         # cfg-4's pool on one GPU (here: 20000 players)
     assert sp["exact"] is True and sp["value"] > 0 and "20000 players" in sp["workload"]
@@ -228,6 +253,37 @@ def test_bench_ranks_dry_run_shards_one_pool(world, oracle_cls):
         ref = run_stream(one, stream_schedule(20000, 0.1, 10.0, 77), mode_weights=(70, 30),
                          role_weights=ROLE_WEIGHTS_5V5, realtime=False)
     assert lm["emission_digest"] == union_digest(ref["digests"])
+
+
+def _dry_cmd(*argv):
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_dryrun_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return [sys.executable, worker] + list(argv), env
+
+
+def test_bench_gpus_n_as_one_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` launched as ONE command with no WORLD_SIZE (the shape of the driver's N = 1 command
+    with another N): bench.py starts the two ranks itself, the line says n_gpus 2 and the collective saw two ranks —
+    it can no longer print an N = 1 number under an `--gpus N` flag ("What's weak" 7)."""
+    import subprocess
+    cmd, env = _dry_cmd("--gpus", "2", "--players", "12000", "--steps", "2", "--warmup", "1", "--no-secondary", "--no-stream")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and "bench.py itself" in d["launched_by"]
+    assert len(d["config"]["sharding"]["per_rank"]) == 2 and d["exactness"]["ok"] is True
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """WORLD_SIZE set by a launcher and different from --gpus: non-zero exit, no line."""
+    import subprocess
+    cmd, env = _dry_cmd("--gpus", "8", "--players", "12000", "--steps", "1", "--warmup", "0")
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 2 and b"WORLD_SIZE=1" in p.stderr
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
 
 
 def test_graft_entry_smoke_dry_run(monkeypatch, capsys):

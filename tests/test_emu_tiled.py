@@ -142,3 +142,40 @@ def test_tiled_rounds_stop_and_go_on(oracle_cls, monkeypatch, env):
     two_ticks(oracle_cls, 7000, seed=21, window=40, regions=3)
     if "MM_PAIR_PINJECT" in env:                          # one long chain as well: ten tiles, the stop in mid-batch
         two_ticks(oracle_cls, 4000, seed=22, window=30, regions=2, lo=0, hi=1400)
+
+
+@pytest.mark.parametrize("env,want", [({}, "clean"), ({"MM_PAIR_PINJECT": "2"}, "inject"), ({"MM_PAIR_PERSIST": "0"}, "off")],
+                         ids=["default", "MM_PAIR_PINJECT=2", "MM_PAIR_PERSIST=0"])
+def test_path_stats_say_which_launch_shapes_a_tick_took(oracle_cls, monkeypatch, env, want):
+    """mm_path_stats_get (include/mm_engine.h): a fall-back of the persistent launch used to leave one MM_PAIR_DEBUG line on
+    stderr and `ok: true` everywhere ("What's weak" 8).  Now the tick's record says how many kp_rounds /
+    kp_round launches it took, which stops it met — each counted ONCE, at the look behind the launch that declared it
+    (PairChain.pfail stays in the record and used to be counted again at every later look of the tick) — and
+    `degraded` when a fall-back was in force.  Results are the oracle's either way."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = make_config([mode_1v1(window=30, region_filter=True)], capacity=16384)
+    rng = np.random.default_rng(31)
+    rating = rng.integers(0, 1401, size=5000).astype(np.int32)        # one chain of ten tiles (PK_T = 512 in this build)
+    cons = cons_make(0, rng.integers(0, 2, size=5000), 0, 0)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        assert a.path_stats()["mode"] == 0xFFFFFFFF and b.path_stats() is None
+        assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+        ma, mb = a.tick(0), b.tick(0)
+        assert_same_tick(ma, mb, "path stats")
+        ps = a.path_stats()
+    assert ps["mode"] == 0 and ps["paths"] == 2 and ps["host_looks"] >= 2
+    assert ps["crit_group"] == 0 and ps["crit_passes"] == ma.stats["passes_max"]
+    assert ps["crit_rounds_passes"] + ps["crit_round_passes"] + ps["crit_late_passes"] == ps["crit_passes"]
+    assert ps["crit_late_lobbies"] <= len(ma) and ps["pair_tiled_passes"] == ps["crit_rounds_passes"] + ps["crit_round_passes"]
+    stops = ps["pair_stops_timeout"] + ps["pair_stops_xcd"] + ps["pair_stops_inject"]
+    assert stops == ps["pair_stops_total"]                            # a fresh engine: every stop of its life was this tick's, once
+    if want == "clean":
+        assert ps["degraded"] == 0 and stops == 0 and ps["pair_rounds_launches"] >= 1 and ps["pair_persist_off"] == 0
+        assert ps["crit_rounds_passes"] == ps["pair_rounds_passes"] > 0 and ps["crit_rounds_hops"] > 0
+    elif want == "inject":
+        assert ps["degraded"] == 1 and ps["pair_stops_inject"] == stops >= 1 and ps["pair_round_launches"] > 0
+        assert stops <= ps["pair_rounds_launches"]                    # one chain: at most one stop per launch
+    else:
+        assert ps["degraded"] == 1 and ps["pair_persist_off"] == 1 and ps["pair_rounds_launches"] == 0 and stops == 0
+        assert ps["crit_rounds_passes"] == 0 and ps["pair_round_launches"] > 0

@@ -559,6 +559,21 @@ def test_gpu_pair_rounds_stop_and_go_on(gpu_cls, oracle_cls, monkeypatch, env):
             assert_same_tick(ma, mb, "rounds %s tick %d" % (env, tick), SCORE_TOL)
             assert_same_state(a, b, cfg, "rounds %s tick %d" % (env, tick))
             live_slots = np.setdiff1d(live_slots, ma.slots.ravel())
+            # mm_path_stats_get: what used to be one MM_PAIR_DEBUG line on stderr is in the tick's record
+            ps = a.path_stats()
+            stops = ps["pair_stops_timeout"] + ps["pair_stops_xcd"] + ps["pair_stops_inject"]
+            assert ps["paths"] & 2 and ps["crit_passes"] == ma.stats["passes_max"]
+            assert ps["crit_rounds_passes"] + ps["crit_round_passes"] + ps["crit_late_passes"] == ps["crit_passes"]
+            if tick == 0:
+                assert stops == ps["pair_stops_total"]             # every stop counted once (not again at the tick's later looks)
+                if not env or "MM_PAIR_PBATCH" in env or "MM_PAIR_PTILES" in env:
+                    assert ps["degraded"] == 0 and stops == 0 and ps["pair_rounds_launches"] >= 1 and ps["crit_rounds_hops"] > 0, ps
+                elif "MM_PAIR_PINJECT" in env:
+                    assert ps["degraded"] == 1 and ps["pair_stops_inject"] >= 1 and ps["pair_stops_timeout"] == 0, ps
+                elif "MM_PAIR_PTIMEOUT_US" in env:
+                    assert ps["degraded"] == 1 and ps["pair_stops_timeout"] >= 1 and ps["pair_round_launches"] > 0, ps
+                else:
+                    assert ps["degraded"] == 1 and ps["pair_persist_off"] == 1 and ps["pair_rounds_launches"] == 0, ps
 
 
 @pytest.mark.gpu

@@ -37,3 +37,25 @@ def test_stream_stops_ingesting_when_the_slot_ring_is_full(oracle_cls):
             s.engine.tick(0)
             out.append((res["full_at_s"], res["ingested"], res["matched"], union_digest(res["digests"])))
     assert out[0] == out[1]
+
+
+def test_precomputed_batches_are_what_the_stream_ingests(oracle_cls, monkeypatch):
+    """`batches=` (bench.py's latency_saturation leg draws the arrivals before its clock starts) replaces the per-tick
+    stream_batch call — it used to be accepted and ignored, so the 5M / 20M players/s legs drew 50 000-200 000 arrivals
+    with numpy inside the real-time loop.  Same emission either way; with batches given the generator is
+    never called."""
+    import microservice_matchmaking_amd.stream as st
+    cfg = make_config([mode_1v1(window=25, region_filter=True)], capacity=1 << 14)
+    sched = stream_schedule(50_000, 0.1, 10.0, 9)
+    with ShardedSearch(cfg, oracle_cls, 0, 1) as s:
+        ref = run_stream(s, sched, realtime=False)
+    batches = [stream_batch(n, sd) for (_, _, n, sd, _) in sched]
+    calls = []
+    real = st.stream_batch
+    monkeypatch.setattr(st, "stream_batch", lambda *a, **k: calls.append(a) or real(*a, **k))
+    with ShardedSearch(cfg, oracle_cls, 0, 1) as s:
+        got = run_stream(s, sched, realtime=False, batches=batches)
+    assert calls == [] and got["digests"] == ref["digests"] and got["matched"] == ref["matched"] > 0
+    with pytest.raises(AssertionError):
+        with ShardedSearch(cfg, oracle_cls, 0, 1) as s:
+            run_stream(s, sched, realtime=False, batches=batches[:-1])

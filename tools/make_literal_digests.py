@@ -34,6 +34,7 @@ from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5, make_pool  # no
 from oracle.literal_ref import SearchStage, find_rating_group_by_rating, team_name  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "literal_64k_digests.json")
+OUT_1M = os.path.join(ROOT, "tests", "golden", "literal_1m_digests.json")
 N = 65536
 
 
@@ -53,6 +54,13 @@ def families():
                                 [("enqueue", 4 * N, 1, {}), ("tick",)]),
         "5v5_w50_roles_256k": ([mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
                                [("enqueue", 4 * N, 1, {"role_weights": ROLE_WEIGHTS_5V5}), ("tick",)]),
+        # BASELINE cfg-2 / cfg-3 THEMSELVES: the bench's 1M pools (seed 1).  The 0-1499 chain holds 300k players = 37 tiles of
+        # 8192: the kp_round -> kp_ask_compact -> kp_rounds hand-over and the 7 chains x 32 tiles XCD map only exist here.
+        # Written to tests/golden/literal_1m_digests.json (OUT_1M); the longest chain is most of an hour of CPython.
+        "1v1_w25_region_1m": ([mode_1v1(window=25, region_filter=True)],
+                              [("enqueue", 1000000, 1, {}), ("tick",)]),
+        "5v5_w50_roles_1m": ([mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
+                             [("enqueue", 1000000, 1, {"role_weights": ROLE_WEIGHTS_5V5}), ("tick",)]),
         # BASELINE cfg-5's mix in one pool, a cancel tick (stale lobbies, purge) and late arrivals
         "mixed_70_30_cancel": ([mode_1v1(window=25, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
                                [("enqueue", N, 1, {"role_weights": ROLE_WEIGHTS_5V5, "mode_weights": (70, 30)}),
@@ -141,23 +149,33 @@ def run_chain(task):
 
 
 def main():
-    want = sys.argv[1:] or list(families())
+    want = sys.argv[1:] or [f for f in families() if not f.endswith("_1m")]
+    out_path = OUT
+    if any(f.endswith("_1m") for f in want):
+        assert all(f.endswith("_1m") for f in want), "the 1M families go to their own file: run them alone"
+        out_path = OUT_1M
     tasks = []
     for fam in want:
         modes, _ = families()[fam]
         for mode in range(len(modes)):
             for gi in range(len(REFERENCE_RATING_GROUPS)):
                 tasks.append((fam, mode, gi))
+    tasks.sort(key=lambda t: {0: 0, 6: 1}.get(t[2], 2))     # the two wide groups first: they are the wall time
     out = {}
-    if os.path.exists(OUT):
-        out = json.load(open(OUT))
+    if os.path.exists(out_path):
+        out = json.load(open(out_path))
     with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
         for fam, mode, gi, ticks, dt in pool.imap_unordered(run_chain, tasks):
             out.setdefault(fam, {})["%d/%d" % (mode, gi)] = ticks
+            for t in ticks:
+                t["literal_seconds"] = round(dt)
             print("%s mode %d group %d: %s lobbies, %.0f s" % (fam, mode, gi, [t["lobbies"] for t in ticks], dt), flush=True)
-    out["_about"] = ("oracle/literal_ref.py on 65 536-player pools, chain by chain; tools/make_literal_digests.py; "
-                     "keys family -> 'mode/group' -> one record per tick")
-    with open(OUT, "w") as f:
+            if out_path == OUT_1M:            # hours of CPU: keep what is done
+                json.dump(out, open(out_path + ".part", "w"), indent=1, sort_keys=True)
+    out["_about"] = ("oracle/literal_ref.py on %s pools, chain by chain; tools/make_literal_digests.py; "
+                     "keys family -> 'mode/group' -> one record per tick"
+                     % ("BASELINE cfg-2 / cfg-3's 1 000 000-player" if out_path == OUT_1M else "65 536-player"))
+    with open(out_path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")
 
