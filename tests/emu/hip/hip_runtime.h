@@ -49,6 +49,8 @@ typedef int hipError_t;
 #define hipSuccess 0
 #define hipErrorInvalidValue 1
 #define hipErrorOutOfMemory 2
+#define hipErrorNotReady 600
+#define hipErrorUnknown 999
 typedef struct emu_stream* hipStream_t;
 typedef struct emu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -68,6 +70,7 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamQuery(hipStream_t s);
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
@@ -101,6 +104,8 @@ static inline long long wall_clock64(void) { return 0; }
 /* relaxed workgroup-scope atomics: plain accesses through a volatile lvalue */
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __HIP_MEMORY_SCOPE_AGENT 3
+#define __HIP_MEMORY_SCOPE_SYSTEM 4
+static inline void __threadfence_system(void) {}
 #define __hip_atomic_load(p, order, scope) (*(const volatile __typeof__(*(p))*)(p))
 #define __hip_atomic_store(p, v, order, scope) ((void)(*(volatile __typeof__(*(p))*)(p) = (v)))
 #define __builtin_amdgcn_readlane(v, l) emu_shfl_i32((v), (l))

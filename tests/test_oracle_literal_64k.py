@@ -4,7 +4,14 @@ long-chain paths: 65 536- and 262 144-player pools (pair tiles from 16 384 playe
 4 096).  The literal code is minutes of Python per chain at these sizes, so it ran once (tools/make_literal_digests.py)
 and its per-chain records are committed in tests/golden/literal_64k_digests.json: emission list (publish order, team
 order), the pass of every lobby, the stored lobby, the queue order after the tick (= requeue order,
-lib/requeue/worker.ex:51-54) and the pair evaluations."""
+lib/requeue/worker.ex:51-54) and the pair evaluations.
+
+Round 5: the same at BASELINE cfg-2 / cfg-3 THEMSELVES — the bench's seeded 1 000 000-player pools (families `*_1m`,
+tests/golden/literal_1m_digests.json).  The first rating group of cfg-2 is a chain of 300 468 players = 37 tiles of
+8192: the hand-over "more than 32 tiles -> kp_round launch by launch -> kp_ask_compact -> kp_rounds on one XCD" and
+the 7 chains x 32 tiles workgroup map only exist at this size, where oracle/mode_r.c had been the sole witness
+("What's weak" 1).  The literal restatement, unchanged, walked them once: 15 minutes of CPython for the
+longest 1v1 chain (149 409 lobbies, 35 M consume/5 calls), the time per chain is in the file (`literal_seconds`)."""
 import json
 import os
 import sys
@@ -15,20 +22,23 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-from make_literal_digests import OUT, cancel_ids, families, h16, script_arrays  # noqa: E402
+from make_literal_digests import OUT, OUT_1M, cancel_ids, families, h16, script_arrays  # noqa: E402
 
 from microservice_matchmaking_amd.config import make_config  # noqa: E402
 from microservice_matchmaking_amd.sharding import rating_groups  # noqa: E402
 
 GOLD = json.load(open(OUT))
+if os.path.exists(OUT_1M):
+    GOLD.update(json.load(open(OUT_1M)))
 SMALL = ["1v1_w25_region", "5v5_w50_roles", "mixed_70_30_cancel"]
 BIG = ["1v1_w25_region_256k", "5v5_w50_roles_256k"]
+HEADLINE = ["1v1_w25_region_1m", "5v5_w50_roles_1m"]          # BASELINE configs[1] / configs[2], bench.py's pools (seed 1)
 
 
 def run_family(engine_cls, fam):
     """The family's script on an ABI engine; the same per-chain records the literal run wrote."""
     modes, steps = families()[fam]
-    cfg = make_config(modes, capacity=1 << 19, timing=False)
+    cfg = make_config(modes, capacity=1 << (20 if fam.endswith("_1m") else 19), timing=False)
     got = {}
     with engine_cls(cfg) as eng:
         batches = iter(script_arrays(steps))
@@ -37,7 +47,7 @@ def run_family(engine_cls, fam):
             if st[0] == "enqueue":
                 first, rating, cons = next(batches)
                 slots = eng.enqueue(rating, cons)
-                # arrival index == slot handle as long as the ring has not wrapped (capacity 2^19)
+                # arrival index == slot handle as long as the ring has not wrapped (capacity 2^19; 2^20 for the 1M pools)
                 assert np.array_equal(slots, np.arange(first, first + len(rating), dtype=np.uint32)), fam
                 waiting.update((int(s), int(s)) for s in slots)
             elif st[0] == "cancel":
@@ -88,15 +98,31 @@ def test_the_chain_routing_of_the_script_is_the_literal_one():
         assert np.array_equal(lit, rating_groups(cfg, rating[:4096]))
 
 
-@pytest.mark.parametrize("fam", SMALL + BIG)
+@pytest.mark.parametrize("fam", SMALL + BIG + HEADLINE)
 def test_oracle_equals_literal_where_the_kernels_branch(oracle_cls, fam):
     if fam not in GOLD:
         pytest.skip("tools/make_literal_digests.py %s has not been run" % fam)
     check(oracle_cls, fam)
 
 
+def test_the_headline_pools_are_the_bench_lines_pools():
+    """The `_1m` families are bench.py's cfg-2 / cfg-3 pools to the player: same generator call, same modes — so the
+    literal digests pin the very workload `value` is quoted on (and `exactness.oracle_digest` of the bench line: the
+    C oracle's emission on this pool, which test_oracle_equals_literal... ties to the literal run chain by chain)."""
+    from microservice_matchmaking_amd.config import mode_1v1, mode_dicts, mode_team
+    from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5, make_pool
+    fams = families()
+    for fam, modes, kw in (("1v1_w25_region_1m", [mode_1v1(window=25, region_filter=True)], {}),
+                           ("5v5_w50_roles_1m", [mode_team(5, 2, 50, (1, 1, 1, 1, 1))], {"role_weights": ROLE_WEIGHTS_5V5})):
+        fmodes, steps = fams[fam]
+        assert mode_dicts(make_config(fmodes, capacity=16)) == mode_dicts(make_config(modes, capacity=16))   # bench.py workload()
+        (first, rating, cons), = script_arrays(steps)
+        r2, c2 = make_pool(1_000_000, seed=1, dist="uniform", **kw)                              # bench.py pool_of()
+        assert first == 0 and np.array_equal(rating, r2) and np.array_equal(cons, c2)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("fam", SMALL + BIG)
+@pytest.mark.parametrize("fam", SMALL + BIG + HEADLINE)
 def test_gpu_equals_literal_where_the_kernels_branch(fam):
     if fam not in GOLD:
         pytest.skip("tools/make_literal_digests.py %s has not been run" % fam)
