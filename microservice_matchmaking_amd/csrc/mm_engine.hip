@@ -2658,6 +2658,15 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                         hp[g].ptm[12] / nr, hp[g].ptm[2] / nr, hp[g].ptm[7] / nr, hp[g].ptm[8] / nr, hp[g].ptm[10] / nr, hp[g].ptm[4] / nr,
                         16.0 * hp[g].ptm[13] / nr, (double)hp[g].ptm[15] / nr);
             }
+        {   // where the last kp_rounds launch ran and where the tables live (run-to-run spread: two modes of the walk, 9.4 / 9.7 ms)
+            unsigned long long xm[MM_MAX_GROUPS * 2u];
+            HIPCHK(e, hipMemcpy(xm, e->d_pk_pbar + MM_MAX_GROUPS, sizeof(xm) / 2u, hipMemcpyDeviceToHost));
+            const uint32_t* const xmask = (const uint32_t*)xm;
+            fprintf(stderr, "[mm-pair] physical XCD mask of each chain's workgroups in the last kp_rounds launch:");
+            for (uint32_t g = 0; g < G; ++g) fprintf(stderr, " g%u=0x%x", g, xmask[g]);
+            fprintf(stderr, " | key %p rec %p %p bitsp %p %p pbar %p stream %p\n", (void*)e->d_pk_key[0], (void*)e->d_pk_scratch, (void*)e->d_pk_rec1,
+                    (void*)e->d_pk_bitsp[0], (void*)e->d_pk_bitsp[1], (void*)e->d_pk_pbar, (void*)e->stream);
+        }
         if (e->pair_tune & 0x2000u) {
             unsigned long long tested = 0, algo = 0;
             for (uint32_t g = 0; g < G; ++g) { tested += hp[g].tested; algo += hp[g].pairs; }
@@ -2799,6 +2808,8 @@ extern "C" int mm_matches(mm_engine* e, uint32_t first, uint32_t count, uint32_t
         if (count == 0) return MM_OK;
         // emission index i of the tick = lobby i - r_pre[g] of group g, stored at r_base[g] + that (tick_impl)
         const uint32_t L = e->r_L;
+        // (Round 5, measured and taken out: the 10 MB of a big tick's list copied by four threads in 256 KB pieces —
+        // 10.01-10.28 ms a step with one thread, 10.03-10.26 with four, profiles/r05_ab_pair_micro.txt.)
         for (uint32_t g = 0; g < e->cfg.n_groups; ++g) {
             const uint32_t lo = e->r_pre[g] > first ? e->r_pre[g] : first;
             const uint32_t hi = e->r_pre[g + 1u] < first + count ? e->r_pre[g + 1u] : first + count;

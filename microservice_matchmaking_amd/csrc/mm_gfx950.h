@@ -85,6 +85,11 @@ static __device__ __forceinline__ uint32_t xld16(const uint16_t* p) { return __h
 static __device__ __forceinline__ unsigned long long xld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // keep the result of a returning atomic alive (the returning form is what makes the wave wait for it)
 #define TW_KEEP(v) asm volatile("" ::"v"(v))
+// The value as the compiler cannot see through: what is derived from it is computed again where it is used instead of
+// being hoisted out of a long loop and kept in registers across it.  kp_rounds<8192> spilled 36 vector registers of
+// loop-invariant LDS addresses (tid + k * 1024, clamped) to scratch and reloaded them, a `s_waitcnt vmcnt(0)` behind each,
+// in the middle of every pass (round 5, found in the ISA).
+#define TW_LAUNDER(v) asm volatile("" : "+v"(v))
 // The walk's fast hops (kp_rounds), tight: from the cursor position p with the REC there (rr), follow "exit anchor whose partner
 // is still queued" from tile to tile while the partner lies BELOW position `lim` — per hop ONE round trip through the scalar cache
 // (the partner's bitmap word and the REC behind the partner) and two dozen scalar instructions; the compiler's version of the same

@@ -36,6 +36,7 @@ static inline void tw_hops(const uint32_t* bits, const uint32_t* rec, uint32_t m
     }
 }
 #define TW_KEEP(v) ((void)(v))
+#define TW_LAUNDER(v) ((void)(v))
 #include <map>
 #define MM_RESIDENT(Type, var)                                                              \
     static std::map<unsigned long long, Type*> var##_all;                                   \
