@@ -885,6 +885,33 @@ __global__ __launch_bounds__(256) void k_pack_results(PackArgs A, const uint32_t
 }
 #define MM_PACK_MAX 8192u            // lobbies of a tick up to which its match list is packed on the device
 
+// The TAIL of a big tick's match list — what the last kernels of the walk emitted, after the last early send — straight
+// into the engine's pinned host buffers, each lobby at its final place (the buffers are device-accessible: hipHostMalloc).
+// It used to leave as three copies per rating group on the copy stream: 21 copy commands of a few KB, 10-12 us apiece
+// one after the other, 0.25 ms behind every tick of cfg-2 (profiles/r05_timeline_gaps_1m_1v1_first.txt).  One launch,
+// coalesced stores over the link, on the engine's own stream: the caller's synchronisation covers it.
+struct TailArgs {
+    uint32_t pre[MM_MAX_GROUPS + 1];                 // prefix of the groups' fresh lobbies
+    uint32_t from[MM_MAX_GROUPS], base[MM_MAX_GROUPS];
+    uint32_t n_groups, L, total, out_slot_stride, out_rec_stride;
+};
+__global__ __launch_bounds__(256) void k_results_tail(TailArgs A, const uint32_t* __restrict__ out_slots,
+                                                      const float* __restrict__ out_score, const uint32_t* __restrict__ out_pass,
+                                                      uint32_t* __restrict__ h_slots, float* __restrict__ h_score, uint32_t* __restrict__ h_pass)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.total) return;
+    uint32_t g = 0;
+    while (g + 1u < A.n_groups && i >= A.pre[g + 1u]) ++g;
+    const uint32_t j = A.from[g] + (i - A.pre[g]);
+    const size_t at = (size_t)A.base[g] + j;
+    const uint32_t* const src = out_slots + (size_t)g * A.out_slot_stride + (size_t)j * A.L;
+    for (uint32_t k = 0; k < A.L; ++k) h_slots[at * A.L + k] = src[k];
+    h_score[at] = out_score[(size_t)g * A.out_rec_stride + j];
+    h_pass[at] = out_pass[(size_t)g * A.out_rec_stride + j];
+}
+#define MM_TAIL_MAX (1u << 20)       // lobbies up to which a tick's tail leaves through k_results_tail (beyond: copy commands)
+
 // A look of the host at the chains' records in the middle of a tick (pair path: after every batch of passes; team path:
 // every 16 passes) is a D2H copy of 3 KB and a stream synchronisation.  The alternative built in round 5 (VERDICT r04,
 // "What's weak" 4) and kept behind MM_LOOK_POLL=1: the records leave by themselves — the last launch of a batch is this
@@ -976,6 +1003,7 @@ struct mm_engine {
     PairChain* h_pchains;      // pinned
     uint32_t* h_look_seq;      // pinned: the sequence number of the last look whose records have arrived (k_look)
     uint32_t look_seq;
+    bool results_tail_kernel;  // MM_RESULTS_TAIL=0: the tail of a tick's match list as copy commands, as before (A/B)
     bool look_poll;            // MM_LOOK_POLL=0: looks as a D2H copy + stream synchronisation, as before (A/B)
     uint32_t ps_hand[4][MM_MAX_GROUPS];   // per rating group at the pair path's last look: passes, lobbies, kp_rounds passes, kp_rounds hops
     mm_path_stats ps;          // mm_path_stats_get: the launch shapes and fall-backs of the last tick (totals carried over)
@@ -1549,6 +1577,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         // time goes — and every polled 1v1 run had ONE step of 17 ms: a host thread that spins for the whole tick is what a
         // container's CPU quota throttles first (a dirty scheduler of the BEAM would fare no better).  MM_LOOK_POLL=1 for A/B.
         { const char* lp = getenv("MM_LOOK_POLL"); e->look_poll = lp && lp[0] == '1'; }
+        { const char* rt = getenv("MM_RESULTS_TAIL"); e->results_tail_kernel = !(rt && rt[0] == '0'); }
         CREATE_CHK(hipHostMalloc((void**)&e->h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault));
         e->h_state.assign(cap, MM_ST_FREE);
         if (e->tk_memb) {
@@ -1872,6 +1901,24 @@ static int results_send(mm_engine* e, const uint32_t* n_out, uint32_t L, uint32_
     if (rc) return rc;
     // the end of a tick with little left to send (every tick of a stream): on the engine's own stream, behind the
     // walk — the caller synchronises that stream anyway, and a second stream's event would be one more round trip
+    if (on_main != nullptr && fresh <= MM_TAIL_MAX && e->results_tail_kernel) {
+        TailArgs A;
+        memset(&A, 0, sizeof(A));
+        A.n_groups = e->cfg.n_groups; A.L = L; A.out_slot_stride = e->out_slot_stride; A.out_rec_stride = e->out_rec_stride;
+        for (uint32_t g = 0; g < e->cfg.n_groups; ++g) {
+            const uint32_t a = e->r_sent[g], b = n_out[g] > a ? n_out[g] : a;
+            A.from[g] = a; A.base[g] = e->r_base[g]; A.pre[g + 1u] = A.pre[g] + (b - a);
+            e->r_sent[g] = b;
+        }
+        A.total = A.pre[e->cfg.n_groups];
+        if (A.total) {
+            hipLaunchKernelGGL(k_results_tail, dim3((A.total + 255u) / 256u), dim3(256), 0, e->stream, A, e->d_out_slots, e->d_out_score,
+                               e->d_out_pass, e->h_rslots, e->h_rscore, e->h_rpass);
+            HIPCHK(e, hipGetLastError());
+        }
+        *on_main = true;                                 // the caller marks the slots after its own synchronisation
+        return MM_OK;
+    }
     const bool main_st = on_main != nullptr && fresh <= 8192u;
     hipStream_t const st = main_st ? e->stream : e->copy_stream;
     for (uint32_t g = 0; g < e->cfg.n_groups; ++g) {

@@ -24,6 +24,8 @@ defmodule Matchmaking.Search.Engine do
   def cancel(_engine, _slots), do: :erlang.nif_error(:nif_not_loaded)
   def tick(_engine, _mode), do: :erlang.nif_error(:nif_not_loaded)
   def queue_depth(_engine, _mode), do: :erlang.nif_error(:nif_not_loaded)
+  # the launch shapes and fall-backs of the last tick: the u32 fields of mm_path_stats (include/mm_engine.h) as a binary
+  def path_stats(_engine), do: :erlang.nif_error(:nif_not_loaded)
   def queue_slots(_engine, _mode, _group), do: :erlang.nif_error(:nif_not_loaded)
   def lobby_state(_engine, _mode, _group), do: :erlang.nif_error(:nif_not_loaded)
   def snapshot(_engine), do: :erlang.nif_error(:nif_not_loaded)

@@ -186,6 +186,19 @@ static ERL_NIF_TERM nif_queue_depth(ErlNifEnv* env, int argc, const ERL_NIF_TERM
     return rc ? err(env, rc) : enif_make_tuple2(env, A_OK, out);
 }
 
+/* path_stats(engine) -> {:ok, <<field::little-32, ...>>}   mm_path_stats_get: the launch shapes and fall-backs of the last
+ * tick, the fields of include/mm_engine.h's mm_path_stats in order (its leading `size` included).  Host state only, no
+ * device call: a plain NIF.  The reference has nothing to put beside it (search/worker.ex:115-117 reports the queue only). */
+static ERL_NIF_TERM nif_path_stats(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+    (void)argc;
+    nif_engine* r; ERL_NIF_TERM out;
+    if (!get_engine(env, argv[0], &r)) return enif_make_badarg(env);
+    mm_path_stats* ps = (mm_path_stats*)enif_make_new_binary(env, sizeof(mm_path_stats), &out);
+    ps->size = (uint32_t)sizeof(mm_path_stats);
+    int rc = mm_path_stats_get(r->e, ps);
+    return rc ? err(env, rc) : enif_make_tuple2(env, A_OK, out);
+}
+
 /* queue_slots(engine, mode, group) -> {:ok, <<slot::little-32, ...>>}   head first: the order the
  * broker would deliver in, requeues at the tail (worker.ex:239-248, requeue/worker.ex:51-54) */
 static ERL_NIF_TERM nif_queue_slots(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
@@ -336,6 +349,7 @@ static ErlNifFunc funcs[] = {
     {"cancel", 2, nif_cancel, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"tick", 2, nif_tick, ERL_NIF_DIRTY_JOB_CPU_BOUND},          /* blocks on the stream until quiescence */
     {"queue_depth", 2, nif_queue_depth, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"path_stats", 1, nif_path_stats, 0},                        /* host state only */
     {"queue_slots", 3, nif_queue_slots, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"lobby_state", 3, nif_lobby_state, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"snapshot", 1, nif_snapshot, ERL_NIF_DIRTY_JOB_IO_BOUND},
