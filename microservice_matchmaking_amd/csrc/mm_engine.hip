@@ -1438,6 +1438,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->team_fused = !(tfe && tfe[0] == '0');                     // 0: kt_emit as a launch of its own behind every chase (cfg-3: +1.3 ms per tick)
             const char* tem = getenv("MM_TEAM_EMIT_MAX");
             e->team_emit_max = tem ? (uint32_t)strtoul(tem, NULL, 0) : TC_EMIT_MAX;   // emitter workgroups per chain and launch at most
+            if (e->team_emit_max > TC_EMIT_MAX) e->team_emit_max = TC_EMIT_MAX;       // (kt_pack resets vis[] for this many workers: TV_AHEAD)
             { const char* tsp = getenv("MM_TEAM_SPLIT"); e->team_split = tsp ? (uint32_t)strtoul(tsp, NULL, 0) : 1u; }
             {   // (read here, once: getenv on the tick's path is neither cheap nor safe beside a setenv of the host process)
                 const char* fw = getenv("MM_TEAM_FWAIT");
@@ -2086,6 +2087,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     P.out_pass = e->d_out_pass;
     const unsigned long long bound64 = e->live_upper < cfg.capacity ? e->live_upper : cfg.capacity;
     const uint32_t bound = (uint32_t)bound64;
+    if (e->pair_tune & 0x10000u) HIPCHK(e, hipMemsetAsync(e->d_pk_grec, 0, (size_t)G * e->pk_gstride * sizeof(uint4), e->stream));   // (diagnostics)
     hipLaunchKernelGGL(kp_init, dim3(G), dim3(1024), 0, e->stream, P, cfg.capacity);
     hipLaunchKernelGGL(kp_pack, dim3((bound + 32u + 1023u) / 1024u, G), dim3(1024), 0, e->stream, P);
     {
@@ -2713,6 +2715,17 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
             for (uint32_t g = 0; g < G; ++g) fprintf(stderr, " g%u=0x%x", g, xmask[g]);
             fprintf(stderr, " | key %p rec %p %p bitsp %p %p pbar %p stream %p\n", (void*)e->d_pk_key[0], (void*)e->d_pk_scratch, (void*)e->d_pk_rec1,
                     (void*)e->d_pk_bitsp[0], (void*)e->d_pk_bitsp[1], (void*)e->d_pk_pbar, (void*)e->stream);
+        }
+        if (e->pair_tune & 0x10000u) {   // every tile's own work per pass inside kp_rounds: who does the chain's barrier wait for?
+            const uint32_t nt = 40u;
+            std::vector<uint4> dg(nt);
+            for (uint32_t g = 0; g < G; ++g) {
+                if (!hp[g].ppass) continue;
+                HIPCHK(e, hipMemcpy(dg.data(), e->d_pk_grec + (size_t)g * e->pk_gstride, nt * sizeof(uint4), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[mm-pair] g%u kp_rounds, cycles from barrier to arrival per tile (passes):", g);
+                for (uint32_t t = 0; t < nt; ++t) if (dg[t].y && dg[t].y != 0xFFFFFFFFu) fprintf(stderr, " t%u=%u(%u)", t, dg[t].x / dg[t].y, dg[t].y);
+                fprintf(stderr, "\n");
+            }
         }
         if (e->pair_tune & 0x2000u) {
             unsigned long long tested = 0, algo = 0;

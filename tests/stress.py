@@ -120,6 +120,8 @@ def main():
                 [scaled(rng.choice([0, 100, 5000, 40000])) for _ in range(int(rng.integers(0, 4)))]
         tag = "seed %d w=%d regions=%d party=%d modes=%d ratings=[%d,%d] sizes=%s" % (
             seed, window, regions, party, len(modes), lo, hi, sizes)
+        if os.environ.get("MM_STRESS_VERBOSE"):
+            print(tag, flush=True)                      # (a crash inside the library leaves no assertion message behind)
         with Engine(cfg) as a, OracleEngine(cfg) as b:
             live = np.zeros(0, np.uint32)
             for j, n in enumerate(sizes):

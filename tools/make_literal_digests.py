@@ -35,6 +35,7 @@ from oracle.literal_ref import SearchStage, find_rating_group_by_rating, team_na
 
 OUT = os.path.join(ROOT, "tests", "golden", "literal_64k_digests.json")
 OUT_1M = os.path.join(ROOT, "tests", "golden", "literal_1m_digests.json")
+OUT_10M = os.path.join(ROOT, "tests", "golden", "literal_10m_digests.json")
 N = 65536
 
 
@@ -61,6 +62,11 @@ def families():
                               [("enqueue", 1000000, 1, {}), ("tick",)]),
         "5v5_w50_roles_1m": ([mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
                              [("enqueue", 1000000, 1, {"role_weights": ROLE_WEIGHTS_5V5}), ("tick",)]),
+        # BASELINE cfg-4's pool (10M players, the shared pool of bench.py --gpus N and of its shared_pool_n1 leg): the 0-1499
+        # chain holds 3.0M players = 367 tiles of 8192 — the second level of the route (kp_group, chains of 64+ tiles) and the
+        # two rounds of workgroups only exist here.  Hours of CPython; tests/golden/literal_10m_digests.json (OUT_10M).
+        "1v1_w25_region_10m": ([mode_1v1(window=25, region_filter=True)],
+                               [("enqueue", 10000000, 1, {}), ("tick",)]),
         # BASELINE cfg-5's mix in one pool, a cancel tick (stale lobbies, purge) and late arrivals
         "mixed_70_30_cancel": ([mode_1v1(window=25, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
                                [("enqueue", N, 1, {"role_weights": ROLE_WEIGHTS_5V5, "mode_weights": (70, 30)}),
@@ -149,11 +155,12 @@ def run_chain(task):
 
 
 def main():
-    want = sys.argv[1:] or [f for f in families() if not f.endswith("_1m")]
+    want = sys.argv[1:] or [f for f in families() if not f.endswith(("_1m", "_10m"))]
     out_path = OUT
-    if any(f.endswith("_1m") for f in want):
-        assert all(f.endswith("_1m") for f in want), "the 1M families go to their own file: run them alone"
-        out_path = OUT_1M
+    for suffix, path in (("_1m", OUT_1M), ("_10m", OUT_10M)):
+        if any(f.endswith(suffix) for f in want):
+            assert all(f.endswith(suffix) for f in want), "the %s families go to their own file: run them alone" % suffix
+            out_path = path
     tasks = []
     for fam in want:
         modes, _ = families()[fam]
@@ -170,11 +177,12 @@ def main():
             for t in ticks:
                 t["literal_seconds"] = round(dt)
             print("%s mode %d group %d: %s lobbies, %.0f s" % (fam, mode, gi, [t["lobbies"] for t in ticks], dt), flush=True)
-            if out_path == OUT_1M:            # hours of CPU: keep what is done
+            if out_path != OUT:               # hours of CPU: keep what is done
                 json.dump(out, open(out_path + ".part", "w"), indent=1, sort_keys=True)
     out["_about"] = ("oracle/literal_ref.py on %s pools, chain by chain; tools/make_literal_digests.py; "
                      "keys family -> 'mode/group' -> one record per tick"
-                     % ("BASELINE cfg-2 / cfg-3's 1 000 000-player" if out_path == OUT_1M else "65 536-player"))
+                     % ("BASELINE cfg-2 / cfg-3's 1 000 000-player" if out_path == OUT_1M else
+                        "BASELINE cfg-4's 10 000 000-player" if out_path == OUT_10M else "65 536-player"))
     with open(out_path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")
