@@ -288,3 +288,31 @@ def test_lobbies_mended_or_looked_up_from_scratch(oracle_cls, monkeypatch, fixma
     rng = np.random.default_rng(35)
     with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
         random_scenario(rng, cfg, a, b, n_rounds=4, batch=1500, cancel_frac=0.05)
+
+
+def test_path_stats_count_the_chunk_flags_that_did_not_come(oracle_cls, monkeypatch):
+    """mm_path_stats_get on the team path: the launches of a tick by kind, and — with the test hook that keeps every third
+    chunk's flag from coming (MM_TEAM_NOWAIT=3) — the anchors the chaser looked up itself, with `degraded` set: a late
+    chunk is a slower pass, and the tick's record says so ("What's weak" 8: 'same for kt_fc chunk time-outs')."""
+    monkeypatch.setenv("MM_TEAM_F2", "0")               # kt_fc from the first pass
+    monkeypatch.setenv("MM_TEAM_LIVE", "1")
+    monkeypatch.setenv("MM_TEAM_LATE", "0")
+    cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 13)
+    from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5, make_pool
+    rating, cons = make_pool(2500, seed=17, role_weights=ROLE_WEIGHTS_5V5)
+    rating = (rating % 1400).astype(np.int32)           # everybody in the first rating group: one chain of ten chunks
+    out = {}
+    for nowait in ("0", "3"):
+        monkeypatch.setenv("MM_TEAM_NOWAIT", nowait)
+        with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+            assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+            ma, mb = a.tick(0), b.tick(0)
+            assert_same_tick(ma, mb, "path stats, nowait " + nowait)
+            out[nowait] = a.path_stats()
+    clean, late = out["0"], out["3"]
+    for ps in (clean, late):
+        assert ps["paths"] == 4 and ps["mode"] == 0 and ps["host_looks"] >= 2 and ps["crit_passes"] == 0
+        assert ps["team_fc_launches"] > 0 and ps["team_f_launches"] == 0 and ps["team_build_launches"] >= 2
+        assert ps["pair_rounds_launches"] == ps["pair_round_launches"] == 0
+    assert clean["team_flags_late"] == 0 and clean["degraded"] == 0
+    assert late["team_flags_late"] > 0 and late["team_flags_late_total"] == late["team_flags_late"] and late["degraded"] == 1

@@ -463,6 +463,12 @@ def test_gpu_team_chaser_without_the_flag_of_a_chunk(gpu_cls, oracle_cls, monkey
             assert_same_tick(ma, mb, "flagless tick %d" % tick, SCORE_TOL)
             assert_same_state(a, b, cfg, "flagless tick %d" % tick)
             live_slots = np.setdiff1d(live_slots, ma.slots.ravel())
+            # mm_path_stats_get: the flags that did not come are counted and the tick says it ran on a fall-back
+            ps = a.path_stats()
+            assert ps["paths"] & 4 and ps["team_fc_launches"] > 0 and ps["team_flags_late"] <= ps["team_flags_late_total"]
+            if "MM_TEAM_NOWAIT" in env and tick == 0:
+                assert ps["team_flags_late"] > 0 and ps["degraded"] == 1, ps
+            assert ps["degraded"] == (1 if ps["team_flags_late"] else 0), ps
     cfg = make_config([mode_team(2, 3, 400, (1, 1), region_filter=True)], capacity=1 << 17)
     with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
         rating, cons = make_pool(60000, seed=73, n_regions=3, role_weights=(3, 2))

@@ -22,26 +22,30 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-from make_literal_digests import OUT, OUT_1M, cancel_ids, families, h16, script_arrays  # noqa: E402
+from make_literal_digests import OUT, OUT_1M, OUT_10M, cancel_ids, families, h16, script_arrays  # noqa: E402
 
 from microservice_matchmaking_amd.config import make_config  # noqa: E402
 from microservice_matchmaking_amd.sharding import rating_groups  # noqa: E402
 
 GOLD = json.load(open(OUT))
-if os.path.exists(OUT_1M):
-    GOLD.update(json.load(open(OUT_1M)))
+for extra in (OUT_1M, OUT_10M):
+    if os.path.exists(extra):
+        GOLD.update(json.load(open(extra)))
 SMALL = ["1v1_w25_region", "5v5_w50_roles", "mixed_70_30_cancel"]
 BIG = ["1v1_w25_region_256k", "5v5_w50_roles_256k"]
-HEADLINE = ["1v1_w25_region_1m", "5v5_w50_roles_1m"]          # BASELINE configs[1] / configs[2], bench.py's pools (seed 1)
+HEADLINE = ["1v1_w25_region_1m", "5v5_w50_roles_1m",           # BASELINE configs[1] / configs[2], bench.py's pools (seed 1)
+            "mixed_70_30_cancel_1m"]                            # configs[4]'s mix at 1M players, three ticks with cancels
 
 
 def run_family(engine_cls, fam):
     """The family's script on an ABI engine; the same per-chain records the literal run wrote."""
     modes, steps = families()[fam]
-    cfg = make_config(modes, capacity=1 << (20 if fam.endswith("_1m") else 19), timing=False)
+    cap_log2 = 21 if fam == "mixed_70_30_cancel_1m" else (20 if fam.endswith("_1m") else (24 if fam.endswith("_10m") else 19))
+    cfg = make_config(modes, capacity=1 << cap_log2, timing=False)
     got = {}
     with engine_cls(cfg) as eng:
         batches = iter(script_arrays(steps))
+        track = any(st[0] == "cancel" for st in steps)   # (who is waiting only matters to a cancel step: 10M dict entries otherwise)
         waiting = {}                                   # global arrival index -> slot
         for st in steps:
             if st[0] == "enqueue":
@@ -49,7 +53,8 @@ def run_family(engine_cls, fam):
                 slots = eng.enqueue(rating, cons)
                 # arrival index == slot handle as long as the ring has not wrapped (capacity 2^19; 2^20 for the 1M pools)
                 assert np.array_equal(slots, np.arange(first, first + len(rating), dtype=np.uint32)), fam
-                waiting.update((int(s), int(s)) for s in slots)
+                if track:
+                    waiting.update((int(s), int(s)) for s in slots)
             elif st[0] == "cancel":
                 ids = cancel_ids(st[1], st[2], waiting.keys())
                 eng.cancel(np.asarray(ids, dtype=np.uint32))
@@ -58,8 +63,9 @@ def run_family(engine_cls, fam):
             else:
                 for mode in range(cfg.n_modes):
                     m = eng.tick(mode)
-                    for s in m.slots.ravel().tolist():
-                        waiting.pop(int(s), None)
+                    if track:
+                        for s in m.slots.ravel().tolist():
+                            waiting.pop(int(s), None)
                     for g in range(cfg.n_groups):
                         sel = m.group == g
                         lobby, _ = eng.lobby_state(mode, g)
@@ -98,7 +104,10 @@ def test_the_chain_routing_of_the_script_is_the_literal_one():
         assert np.array_equal(lit, rating_groups(cfg, rating[:4096]))
 
 
-@pytest.mark.parametrize("fam", SMALL + BIG + HEADLINE)
+POOL_10M = ["1v1_w25_region_10m"]                              # BASELINE configs[3]'s pool (bench.py --gpus N, shared_pool_n1)
+
+
+@pytest.mark.parametrize("fam", SMALL + BIG + HEADLINE + POOL_10M)
 def test_oracle_equals_literal_where_the_kernels_branch(oracle_cls, fam):
     if fam not in GOLD:
         pytest.skip("tools/make_literal_digests.py %s has not been run" % fam)
@@ -122,7 +131,7 @@ def test_the_headline_pools_are_the_bench_lines_pools():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fam", SMALL + BIG + HEADLINE)
+@pytest.mark.parametrize("fam", SMALL + BIG + HEADLINE + POOL_10M)
 def test_gpu_equals_literal_where_the_kernels_branch(fam):
     if fam not in GOLD:
         pytest.skip("tools/make_literal_digests.py %s has not been run" % fam)

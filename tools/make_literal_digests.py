@@ -62,6 +62,14 @@ def families():
                               [("enqueue", 1000000, 1, {}), ("tick",)]),
         "5v5_w50_roles_1m": ([mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
                              [("enqueue", 1000000, 1, {"role_weights": ROLE_WEIGHTS_5V5}), ("tick",)]),
+        # BASELINE cfg-5's 70/30 mix at 1M players with cancels: tick, every 16th waiting player cancelled, tick (stale lobbies, purge,
+        # heads that sit out), 131 072 late arrivals, every 32nd cancelled, tick — the cancel paths of the long-chain kernels
+        # (kp_init's pos0 / extra0, kt_init's sit-out, k_purge over 300k-player queues) at the size the 1M families pin the plain tick
+        "mixed_70_30_cancel_1m": ([mode_1v1(window=25, region_filter=True), mode_team(5, 2, 50, (1, 1, 1, 1, 1))],
+                                  [("enqueue", 1000000, 1, {"role_weights": ROLE_WEIGHTS_5V5, "mode_weights": (70, 30)}),
+                                   ("tick",), ("cancel", 7, 16), ("tick",),
+                                   ("enqueue", 131072, 2, {"role_weights": ROLE_WEIGHTS_5V5, "mode_weights": (70, 30)}),
+                                   ("cancel", 8, 32), ("tick",)]),
         # BASELINE cfg-4's pool (10M players, the shared pool of bench.py --gpus N and of its shared_pool_n1 leg): the 0-1499
         # chain holds 3.0M players = 367 tiles of 8192 — the second level of the route (kp_group, chains of 64+ tiles) and the
         # two rounds of workgroups only exist here.  Hours of CPython; tests/golden/literal_10m_digests.json (OUT_10M).
