@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stream --no-secondary --no-boundary"
 for MODE in 1v1 5v5; do
   [ "$WHAT" = both ] || [ "$WHAT" = "$MODE" ] || continue
-  if [ $MODE = 1v1 ]; then FIRST=kp_init; KERNELS="kp_round kp_group kp_late kp_nx_init kp_finish"; PFX="kp_,kc_"; TJ=traffic_latest.json
+  if [ $MODE = 1v1 ]; then FIRST=kp_init; KERNELS="kp_rounds kp_round kp_group kp_late kp_nx_init kp_init kp_finish"; PFX="kp_,kc_"; TJ=traffic_latest.json
   else FIRST=kt_init; KERNELS="kt_build kt_fc kt_f kt_f2 kt_chase kt_emit kt_late"; PFX="kt_"; TJ=traffic_latest_5v5.json; fi
   rm -rf /tmp/prof_$MODE && rocprofv3 --kernel-trace -d /tmp/prof_$MODE -- $BENCH --mode $MODE > /dev/null 2> "$OUT/rocprof_$MODE.err"
   DB=$(find /tmp/prof_$MODE -name "*_results.db" | head -1)
