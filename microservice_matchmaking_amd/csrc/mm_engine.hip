@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void k_pack_results(PackArgs A, const uint32_t
 // The TAIL of a big tick's match list — what the last kernels of the walk emitted, after the last early send — straight
 // into the engine's pinned host buffers, each lobby at its final place (the buffers are device-accessible: hipHostMalloc).
 // It used to leave as three copies per rating group on the copy stream: 21 copy commands of a few KB, 10-12 us apiece
-// one after the other, 0.25 ms behind every tick of cfg-2 (profiles/r05_timeline_gaps_1m_1v1_first.txt).  One launch,
+// one after the other, 0.25 ms behind every tick of cfg-2 (profiles/r05_timeline_gaps_1m_1v1.txt of the round's first call).  One launch,
 // coalesced stores over the link, on the engine's own stream: the caller's synchronisation covers it.
 struct TailArgs {
     uint32_t pre[MM_MAX_GROUPS + 1];                 // prefix of the groups' fresh lobbies
@@ -998,6 +998,7 @@ struct mm_engine {
     uint32_t* d_pack;          // the packed match list of a small tick (k_pack_results)
     uint4* d_pk_grec;          // second level of the route (kp_group)
     uint32_t pk_gstride;
+    uint32_t pair_nxseg;       // MM_PAIR_NXSEG: anchors per workgroup of kp_nx_init (0: 2048, or 256 for a small pool)
     bool pair_xcd;             // MM_PAIR_XCD=0: kp_round on the plain (tile, group) grid (A/B)
     uint32_t pair_group_min;   // MM_PAIR_GROUP: tiles of the longest chain from which a batch runs with the second level (0 = never)
     PairChain* h_pchains;      // pinned
@@ -1421,6 +1422,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_ptimeout[1] = e->pair_ptimeout[0] * 40u;
             e->pair_pcool = 0;
             e->pair_pstops = 0;
+            { const char* nxs = getenv("MM_PAIR_NXSEG"); e->pair_nxseg = nxs ? (uint32_t)strtoul(nxs, NULL, 0) : 0u;
+              if (e->pair_nxseg && (e->pair_nxseg < 64u || e->pair_nxseg > NXI_SEG)) e->pair_nxseg = 0u; }
             const char* ppb = getenv("MM_PAIR_PBATCH");
             e->pair_pbatch = ppb && atoi(ppb) > 0 ? (uint32_t)atoi(ppb) : 48u;       // 48 / 64 / 96 measured: 95.7 / 94.6 / 93.5 M matched players/s (gpurun_out/ab_r4f.jsonl)
             const char* pb = getenv("MM_PAIR_BATCH");
@@ -2094,7 +2097,8 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
         // a workgroup walks its anchors eight at a time (one wave each): 2048 anchors per workgroup keep a big pool's staging
         // traffic low, but a stream's tick has a few hundred players per chain, all in ONE workgroup then (147 us per tick
         // measured) — 256 anchors per workgroup while the pool is small
-        const uint32_t seg = bound <= 65536u ? 256u : NXI_SEG;
+        uint32_t seg = bound <= 65536u ? 256u : NXI_SEG;
+        if (e->pair_nxseg) seg = e->pair_nxseg;               // MM_PAIR_NXSEG (experiments: anchors per workgroup of kp_nx_init)
         hipLaunchKernelGGL(kp_nx_init, dim3((bound + seg - 1u) / seg + 1u, G), dim3(NXI_THREADS), 0, e->stream, P, seg);
     }
     HIPCHK(e, hipGetLastError());

@@ -287,8 +287,15 @@ defmodule Matchmaking.Search.EngineOwner do
         {:ok, fd} = :file.open(journal_path(state, last), [:append, :raw, :binary])
         state = %{state | journal: fd}
         pending = for payload <- payloads, do: {payload, %{delivery_tag: nil}, :replay}
-        # ingest/1 without acks (channel :replay) and without journalling again (the records are on disk already)
-        ingest(%{state | pending: Enum.reverse(pending), journal: nil}) |> Map.put(:journal, fd)
+        # ingest/1 without acks (channel :replay) and without journalling again (the records are on disk already).  Every
+        # replayed payload held a slot when it was journalled: one that finds none now (a pool filled by restore + replay:
+        # mm_enqueue refuses the whole batch, the match in ingest/1 fails; a row refused on its own comes back as 0xFFFFFFFF)
+        # must not vanish with its journal generation — init fails instead, the journal files stay (ADVICE r04)
+        held = :ets.info(state.slots, :size)
+        state = ingest(%{state | pending: Enum.reverse(pending), journal: nil}) |> Map.put(:journal, fd)
+        if :ets.info(state.slots, :size) - held != length(payloads),
+          do: raise("replay: #{length(payloads) - (:ets.info(state.slots, :size) - held)} acked players found no slot")
+        state
     end
   end
 
