@@ -221,7 +221,9 @@ __global__ __launch_bounds__(BK_THREADS) void k_bucket_scan(uint32_t n_rows, uin
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t per = (n_rows + BK_THREADS - 1) / BK_THREADS;
     const uint32_t r0 = dev_min_u32(tid * per, n_rows), r1 = dev_min_u32(r0 + per, n_rows);
-    for (uint32_t c = 0; c < n_chains; ++c) {
+    // one workgroup per chain (round 5: one workgroup went through the chains one after the other, 33 us for seven)
+    {
+        const uint32_t c = blockIdx.x;
         uint32_t s = 0;
         for (uint32_t r = r0; r < r1; ++r) s += wave_hist[r * n_chains + c];
         const uint32_t incl = wave_incl_scan(s, lane);
@@ -998,7 +1000,8 @@ struct mm_engine {
     uint32_t* d_pack;          // the packed match list of a small tick (k_pack_results)
     uint4* d_pk_grec;          // second level of the route (kp_group)
     uint32_t pk_gstride;
-    uint32_t pair_nxseg;       // MM_PAIR_NXSEG: anchors per workgroup of kp_nx_init (0: 2048, or 256 for a small pool)
+    uint32_t pair_nxseg;       // MM_PAIR_NXSEG: anchors per workgroup of kp_nx_init (0: 256)
+    uint32_t pair_nxstage;     // MM_PAIR_NXSTAGE: entries it stages in LDS, anchors included (0: NXI_STAGE)
     bool pair_xcd;             // MM_PAIR_XCD=0: kp_round on the plain (tile, group) grid (A/B)
     uint32_t pair_group_min;   // MM_PAIR_GROUP: tiles of the longest chain from which a batch runs with the second level (0 = never)
     PairChain* h_pchains;      // pinned
@@ -1423,7 +1426,8 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
             e->pair_pcool = 0;
             e->pair_pstops = 0;
             { const char* nxs = getenv("MM_PAIR_NXSEG"); e->pair_nxseg = nxs ? (uint32_t)strtoul(nxs, NULL, 0) : 0u;
-              if (e->pair_nxseg && (e->pair_nxseg < 64u || e->pair_nxseg > NXI_SEG)) e->pair_nxseg = 0u; }
+              if (e->pair_nxseg && (e->pair_nxseg < 64u || e->pair_nxseg > NXI_SEG)) e->pair_nxseg = 0u;
+              const char* nxt = getenv("MM_PAIR_NXSTAGE"); e->pair_nxstage = nxt ? (uint32_t)strtoul(nxt, NULL, 0) : 0u; }
             const char* ppb = getenv("MM_PAIR_PBATCH");
             e->pair_pbatch = ppb && atoi(ppb) > 0 ? (uint32_t)atoi(ppb) : 48u;       // 48 / 64 / 96 measured: 95.7 / 94.6 / 93.5 M matched players/s (gpurun_out/ab_r4f.jsonl)
             const char* pb = getenv("MM_PAIR_BATCH");
@@ -1669,7 +1673,7 @@ static int enqueue_device_impl(mm_engine* e, uint32_t n, const int32_t* d_rating
     if (timing) HIPCHK(e, hipEventRecord(e->ev[0], e->stream));
     hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(BK_THREADS), 0, e->stream, n, d_rating, d_cons, d_group, B,
                        e->n_chains, e->d_wave_hist, e->d_counters + 1);
-    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(BK_THREADS), 0, e->stream, (uint32_t)rows, e->n_chains,
+    hipLaunchKernelGGL(k_bucket_scan, dim3(e->n_chains), dim3(BK_THREADS), 0, e->stream, (uint32_t)rows, e->n_chains,
                        e->d_wave_hist, e->d_chains, e->cfg.capacity);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(BK_THREADS), 0, e->stream, n, d_rating, d_cons, d_group, B,
                        e->n_chains, e->d_wave_hist, e->next_slot, d_slot_sel, e->d_q_rating, e->d_q_cons, e->d_q_slot,
@@ -2094,12 +2098,20 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
     hipLaunchKernelGGL(kp_init, dim3(G), dim3(1024), 0, e->stream, P, cfg.capacity);
     hipLaunchKernelGGL(kp_pack, dim3((bound + 32u + 1023u) / 1024u, G), dim3(1024), 0, e->stream, P);
     {
-        // a workgroup walks its anchors eight at a time (one wave each): 2048 anchors per workgroup keep a big pool's staging
-        // traffic low, but a stream's tick has a few hundred players per chain, all in ONE workgroup then (147 us per tick
-        // measured) — 256 anchors per workgroup while the pool is small
-        uint32_t seg = bound <= 65536u ? 256u : NXI_SEG;
-        if (e->pair_nxseg) seg = e->pair_nxseg;               // MM_PAIR_NXSEG (experiments: anchors per workgroup of kp_nx_init)
-        hipLaunchKernelGGL(kp_nx_init, dim3((bound + seg - 1u) / seg + 1u, G), dim3(NXI_THREADS), 0, e->stream, P, seg);
+        // A workgroup walks its anchors eight at a time (one wave each).  256 anchors per workgroup (round 5; 2048 until then,
+        // "to keep a big pool's staging traffic low"): the kernel is bound by instruction issue, the anchors of the wide rating
+        // groups cost 2-3x those of the narrow ones, and 147 + 98 heavy workgroups of 2048 anchors landed four to a CU —
+        // 299 us for the 1M pool against 148 us with 256 anchors a workgroup (157 / 173 us with 512 / 1024;
+        // profiles/r05_ab_nx_seg.txt).  The staged window (NXI_STAGE entries from L2) is read 8192 / 256 times per entry: 130 MB.
+        // (a 10M pool keeps its 2048: the grid is sized by the POOL for every rating group — the host does not know the chains'
+        // lengths yet — and a quarter of a million workgroups that only find out they have nothing to do are not free)
+        uint32_t seg = 256u, stage = NXI_STAGE;
+        while (seg < NXI_SEG && (unsigned long long)bound > 8192ull * seg) seg <<= 1;
+        if (e->pair_nxseg) seg = e->pair_nxseg;               // MM_PAIR_NXSEG / MM_PAIR_NXSTAGE (experiments)
+        if (e->pair_nxstage) stage = e->pair_nxstage;
+        if (stage < seg + 64u) stage = seg + 64u;
+        if (stage > NXI_STAGE) stage = NXI_STAGE;
+        hipLaunchKernelGGL(kp_nx_init, dim3((bound + seg - 1u) / seg + 1u, G), dim3(NXI_THREADS), 0, e->stream, P, seg, stage);
     }
     HIPCHK(e, hipGetLastError());
     uint32_t tail_no[MM_MAX_GROUPS];
