@@ -2722,6 +2722,9 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                         g, hp[g].ppass, e->pair_pstops, nr, hp[g].ptm[0] / nr, hp[g].ptm[3] / nr, hp[g].ptm[6] / nr, hp[g].ptm[9] / nr, hp[g].ptm[1] / nr,
                         hp[g].ptm[12] / nr, hp[g].ptm[2] / nr, hp[g].ptm[7] / nr, hp[g].ptm[8] / nr, hp[g].ptm[10] / nr, hp[g].ptm[4] / nr,
                         16.0 * hp[g].ptm[13] / nr, (double)hp[g].ptm[15] / nr);
+                fprintf(stderr, "[mm-pair] g%u kp_rounds, tile 1's walker off the fast path: %u hops whose partner had left, %.0f cycles each; %u hops without a partner inside the horizon, %.0f cycles each\n",
+                        g, hp[g].pslow[0], hp[g].pslow[0] ? 16.0 * hp[g].pslow[1] / hp[g].pslow[0] : 0.0, hp[g].pslow[2],
+                        hp[g].pslow[2] ? 16.0 * hp[g].pslow[3] / hp[g].pslow[2] : 0.0);
             }
         {   // where the last kp_rounds launch ran and where the tables live (run-to-run spread: two modes of the walk, 9.4 / 9.7 ms)
             unsigned long long xm[MM_MAX_GROUPS * 2u];
