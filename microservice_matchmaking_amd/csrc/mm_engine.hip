@@ -2266,7 +2266,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                     const uint32_t slots = pair_xcd_map(P, tof, G, true);
                     if (slots) {
                         P.grp = 0;
-                        HIPCHK(e, hipMemsetAsync(e->d_pk_pbar, 0, (size_t)MM_MAX_GROUPS * 2u * sizeof(unsigned long long) + 64u, e->stream));
+                        // (the arrival words are zero: kp_init at the start of the tick, kc_commit behind every batch)
                         // (the batch ends by itself when the longest chain can be compacted into shorter tiles: it may be long)
                         const uint32_t K = e->pair_pbatch, slice = MM_PERSIST_SLICE ? MM_PERSIST_SLICE : K + 1u;
                         for (uint32_t it = 0; it <= K; it += slice)
@@ -2727,11 +2727,8 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                         hp[g].pslow[2] ? 16.0 * hp[g].pslow[3] / hp[g].pslow[2] : 0.0);
             }
         {   // where the last kp_rounds launch ran and where the tables live (run-to-run spread: two modes of the walk, 9.4 / 9.7 ms)
-            unsigned long long xm[MM_MAX_GROUPS * 2u];
-            HIPCHK(e, hipMemcpy(xm, e->d_pk_pbar + MM_MAX_GROUPS, sizeof(xm) / 2u, hipMemcpyDeviceToHost));
-            const uint32_t* const xmask = (const uint32_t*)xm;
-            fprintf(stderr, "[mm-pair] physical XCD mask of each chain's workgroups in the last kp_rounds launch:");
-            for (uint32_t g = 0; g < G; ++g) fprintf(stderr, " g%u=0x%x", g, xmask[g]);
+            fprintf(stderr, "[mm-pair] physical XCD mask of each chain's workgroups in its last kp_rounds launch:");
+            for (uint32_t g = 0; g < G; ++g) fprintf(stderr, " g%u=0x%x", g, hp[g].pxm);
             fprintf(stderr, " | key %p rec %p %p bitsp %p %p pbar %p stream %p\n", (void*)e->d_pk_key[0], (void*)e->d_pk_scratch, (void*)e->d_pk_rec1,
                     (void*)e->d_pk_bitsp[0], (void*)e->d_pk_bitsp[1], (void*)e->d_pk_pbar, (void*)e->stream);
         }
