@@ -2122,6 +2122,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
         uint32_t tiles = (bound + PK_T - 1u) / PK_T + 1u;
         if (tiles > e->pk_max_tiles) tiles = e->pk_max_tiles;
         bool after_persist = false;            // the look directly behind a kp_rounds launch: only there is PairChain.pfail news
+        uint32_t last_tp = 0;                  // the tile length of the tick's last batch (it never grows: below)
         for (uint32_t guard = 0;; ++guard) {
             // A pass without a change ends a chain, so a chain has at most `capacity` passes; an iteration retires at least one
             // pass of every tiled chain, or is one of the few kinds that retire none and are each followed by one that does
@@ -2222,10 +2223,27 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             if (persist && e->pair_pcool) { --e->pair_pcool; persist = false; e->ps.degraded = 1; }
             // (a batch that kp_rounds would have taken, walked launch by launch because it is off: a fall-back's timing)
             if (e->pair_fused && !e->pair_persist && !compact && (longest + PK_TMAX - 1u) / PK_TMAX <= e->pair_ptiles) e->ps.degraded = 1;
-            const uint32_t tiles_max = persist && e->pair_ptiles < e->pair_tiles_max ? e->pair_ptiles : e->pair_tiles_max;
+            // ONE cap for the tile count whether this batch is kp_rounds' or kp_round's (round 5): the tile length of a tick must
+            // never GROW.  An entry next[i] = NX_FAR says "nobody fits inside the horizon", and the horizon is two tiles of the
+            // length it was computed at; the walk resolves it by scanning from the end of the CURRENT horizon — right for an
+            // equal or shorter tile length (it scans a superset), wrong for a longer one (the stretch between the two horizons
+            // is never looked at: a later partner, or none).  Until round 5 a kp_round batch was sized for 40 tiles and a
+            // kp_rounds batch for 32: a chain of 33-40 tiles of length T walked launch by launch — the cool-down after a stop of
+            // kp_rounds, or while ANOTHER chain was still too long for kp_rounds — came back to kp_rounds at 2 T.  Found by
+            // tests/stress.py with MM_PAIR_PTILES=5 (seed 130203984: 46 lobbies of one chain missing), on the device and on
+            // the shim; it needs a stop of kp_rounds (or the knob) to happen, which is why no default run ever met it.
+            const uint32_t cap_p = e->pair_ptiles < e->pair_tiles_max ? e->pair_ptiles : e->pair_tiles_max;
+            const uint32_t tiles_max = (e->pair_fused && e->pair_persist) ? cap_p : e->pair_tiles_max;
             if (e->pair_fused && !e->pair_tile_fixed)
                 for (uint32_t cand = PK_TMAX / 4u; cand < PK_TMAX; cand <<= 1)    // (an eighth was measured: slower, the fixed cost of a round takes over)
                     if ((longest + cand - 1u) / cand <= tiles_max) { tp = cand; break; }
+            if (last_tp && tp > last_tp && !compact) {
+                // (the cap changed in mid-tick — kp_rounds turned off for good by a PF_XCD stop — or a knob: every tiled chain is
+                // compacted first, which turns its NX_FAR entries into "not computed")
+                hipLaunchKernelGGL(kp_ask_compact, dim3(G), dim3(64), 0, e->stream, P, 0xFFFFFFFFu);
+                compact = true;
+                last_tp = 0;
+            }
             tiles = (longest + tp - 1u) / tp;
 #define TILE_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                                              \
     do {                                                                                                                   \
@@ -2248,6 +2266,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 HIPCHK(e, hipGetLastError());
                 continue;                       // look at the new lengths before the next batch
             }
+            last_tp = tp;
             for (uint32_t g = 0; g < G; ++g) P.pyq[g] = 0;
             P.pyq[yield_g] = yield_q;
             if (e->pair_fused) {

@@ -101,9 +101,14 @@ def main():
     t_end = time.time() + budget
     n_done = 0
     k = 0
+    only = os.environ.get("MM_STRESS_ONLY")              # one scenario by its seed (what a failure's message names)
     while time.time() < t_end:
         seed = seed0 * 100003 + k
         k += 1
+        if only:
+            if k > 1:
+                break
+            seed = int(only)
         rng = np.random.default_rng(seed)
         window = int(rng.choice([0, 1, 3, 10, 25, 60, 200, 1000, 10 ** 6]))
         regions = int(rng.choice([1, 2, 4, 8, 64]))

@@ -179,3 +179,30 @@ def test_path_stats_say_which_launch_shapes_a_tick_took(oracle_cls, monkeypatch,
     else:
         assert ps["degraded"] == 1 and ps["pair_persist_off"] == 1 and ps["pair_rounds_launches"] == 0 and stops == 0
         assert ps["crit_rounds_passes"] == 0 and ps["pair_round_launches"] > 0
+
+
+@pytest.mark.parametrize("seed", [18, 21, 39])
+def test_the_tile_length_of_a_tick_never_grows(oracle_cls, monkeypatch, seed):
+    """Two chains of similar length, sparse fits, kp_rounds limited to four tiles (MM_PAIR_PTILES=4).  Both start too long
+    for kp_rounds and are walked launch by launch at the SHORT tile length (the cap of a kp_round batch was ten tiles
+    here, forty in the product); the longer one is compacted when it fits, the other keeps the batches launch by launch
+    for a while — and the first one's fresh next[] entries say NX_FAR, "nobody inside the horizon of two SHORT tiles";
+    when the second fits as well, kp_rounds took over at the LONG tile length (its own cap), where the walk resolves
+    NX_FAR from the end of two long tiles: the stretch in between was never looked at — a later partner, or none.
+    Found in round 5 by tests/stress.py with MM_PAIR_PTILES=5 on the device (seed 130203984: 46 lobbies of one chain
+    missing; round 4's sources did the same); in the product the same growth needs a kp_rounds stop and its cool-down.
+    One cap for both kinds of batch now, and a guard that compacts every tiled chain should a tile length grow all the
+    same.  These three seeds differed from the oracle on round 4's build of this geometry."""
+    monkeypatch.setenv("MM_PAIR_PTILES", "4")
+    rng = np.random.default_rng(seed)
+    ra, rb = rng.integers(4000, 5001, size=2560), rng.integers(0, 1500, size=2500)
+    rating = np.concatenate([ra, rb]).astype(np.int32)
+    rating = rating[rng.permutation(rating.size)]
+    cons = cons_make(np.zeros(rating.size, np.int64), rng.integers(0, 16, size=rating.size), 0, 0)
+    cfg = make_config([mode_1v1(window=25, region_filter=True)], capacity=1 << 14)
+    with EmuEngineSmall(cfg) as a, oracle_cls(cfg) as b:
+        assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+        assert_same_tick(a.tick(0), b.tick(0), "tile length growth, seed %d" % seed)
+        assert_same_state(a, b, cfg, "tile length growth, seed %d" % seed)
+        ps = a.path_stats()
+        assert ps["pair_round_launches"] > 0 and ps["pair_rounds_launches"] > 0      # both kinds of batch were in the tick

@@ -583,6 +583,27 @@ def test_gpu_pair_rounds_stop_and_go_on(gpu_cls, oracle_cls, monkeypatch, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ptiles", ["5", "6"])
+def test_gpu_tile_length_never_grows_within_a_tick(gpu_cls, oracle_cls, monkeypatch, ptiles):
+    """The pool tests/stress.py failed on with MM_PAIR_PTILES=5 in round 5 (and on round 4's sources): 260 000 players over
+    all seven rating groups, +-60, 64 regions — sparse fits, so many next[] entries say NX_FAR.  With kp_rounds limited to
+    five (six) tiles the two longest chains take turns in being too long for it; the batches in between were sized for
+    forty tiles of 2048 positions, and kp_rounds then took over at 8192: NX_FAR entries computed for the short horizon
+    were resolved from the end of the long one (tests/test_emu_tiled.py::test_the_tile_length_of_a_tick_never_grows has
+    the mechanism).  46 lobbies of the 4000-5000 group were missing."""
+    monkeypatch.setenv("MM_PAIR_PTILES", ptiles)
+    rng = np.random.default_rng(130203984)
+    n = 260000
+    rating = rng.integers(0, 5001, size=n).astype(np.int32)
+    cons = cons_make(np.zeros(n, np.int64), rng.integers(0, 64, size=n), 0, 0)
+    cfg = make_config([mode_1v1(window=60, region_filter=True)], capacity=1 << 19)
+    with gpu_cls(cfg) as a, oracle_cls(cfg) as b:
+        assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
+        assert_same_tick(a.tick(0), b.tick(0), "tile length growth, MM_PAIR_PTILES=" + ptiles, SCORE_TOL)
+        assert_same_state(a, b, cfg, "tile length growth")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["1v1", "5v5"])
 def test_gpu_two_engines_tick_concurrently(gpu_cls, oracle_cls, mode):
     """Two engines on one GPU, ticking at the same time from two host threads (own streams, own device memory): the 1v1
