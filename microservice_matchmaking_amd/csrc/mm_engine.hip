@@ -2132,6 +2132,14 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             { int lrc = look_launch(e, e->d_pchains, e->h_pchains, G * sizeof(PairChain)); if (lrc) return lrc; }
             { int lrc = look_wait(e); if (lrc) return lrc; }
             ++e->ps.host_looks;
+            if (e->pair_debug && guard >= 200u && guard % 200u == 0u) {           // (a tick that looks at its chains hundreds of times)
+                fprintf(stderr, "[mm-pair] look %u: cool-down %u, persist %d, last tile length %u;", guard, e->pair_pcool, (int)e->pair_persist, last_tp);
+                for (uint32_t g = 0; g < G; ++g) {
+                    const PairChain& pc = e->h_pchains[g];
+                    if (pc.fast) fprintf(stderr, " g%u[stage %u m %u qlen %u passes %u compact %u pfail 0x%x]", g, pc.stage, pc.m, pc.qlen, pc.passes, pc.want_compact, pc.pfail);
+                }
+                fprintf(stderr, "\n");
+            }
             bool tiled = false, compact = false;
             uint32_t longest = 0;
             for (uint32_t g = 0; g < G; ++g) {
