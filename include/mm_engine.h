@@ -169,6 +169,73 @@ int mm_find_rating_group(const mm_config* cfg, double rating, uint32_t* group);
 int  mm_engine_create(const mm_config* cfg, mm_engine** out);
 void mm_engine_destroy(mm_engine* e); /* NULL-safe; NIF resource destructor */
 
+/* ---- per-engine tuning (round 6) ---------------------------------------------------
+ * How an engine walks — batch sizes, which persistent launch shapes it may use, the bounded waits,
+ * the test hooks — never WHAT it computes: every setting gives the same lobbies in the same order
+ * (tests/stress.py --fuzz-knobs draws them at random and compares with the oracle).  The reference's
+ * counterpart is the per-worker Confex configuration read in Search.Worker.init/1
+ * (lib/search/worker.ex:54-66, :220-237; config/config.exs:11-25): a property of ONE worker, not of
+ * the node.  Until round 5 these were process-wide MM_* environment variables read at create, so two
+ * engines of one BEAM node could not differ; now the environment only supplies the DEFAULTS
+ * (mm_tuning_default), and the owner passes the record to mm_engine_create_ex.
+ *
+ * Size-versioned like mm_path_stats: the caller sets `size` to its sizeof(mm_tuning); fields it does
+ * not know keep their defaults.  Every field is a uint32_t so that a binding can treat the record as
+ * words and address fields by NAME (mm_tuning_set / mm_tuning_name) without mirroring the layout. */
+typedef struct mm_tuning {
+    uint32_t size;              /* in: sizeof(mm_tuning) of the caller                                          */
+    /* general */
+    uint32_t force_generic;     /* 1: every chain is walked by k_walk (the pair and team paths off)  MM_FORCE_GENERIC   [0]  */
+    uint32_t debug;             /* 1: per-tick diagnostics on stderr, phase timers in the kernels    MM_PAIR_DEBUG      [0]  */
+    uint32_t results_early;     /* 1: the match list leaves for the host while the walk still runs   MM_RESULTS_EARLY   [1]  */
+    uint32_t results_tail;      /* 1: the tail of the match list by ONE kernel into pinned memory    MM_RESULTS_TAIL    [1]  */
+    uint32_t look_poll;         /* 1: looks at the chains through a polled pinned word, not a copy   MM_LOOK_POLL       [0]  */
+    uint32_t fail_tick;         /* test hook: the k-th mm_tick fails after its walk (0: never)        MM_DEBUG_FAIL_TICK [0]  */
+    /* pair path (mm_pair.inc) */
+    uint32_t pair_persist;      /* 1: several passes per launch (kp_rounds) where a chain fits one XCD MM_PAIR_PERSIST   [1]  */
+    uint32_t pair_ptiles;       /* tiles of the longest chain a kp_rounds batch may have, 1..32       MM_PAIR_PTILES     [32] */
+    uint32_t pair_pbatch;       /* passes per kp_rounds launch at most, 1..4096                       MM_PAIR_PBATCH     [48] */
+    uint32_t pair_batch;        /* kp_round launches per look of the host at the chains, 1..4096      MM_PAIR_BATCH      [48] */
+    uint32_t pair_ptimeout_us;  /* what a workgroup waits at a launch's first barrier (40x later), us MM_PAIR_PTIMEOUT_US [5000] */
+    uint32_t pair_pinject;      /* test hook: a kp_rounds launch declares a stop at this iteration + 1 (0: never) MM_PAIR_PINJECT [0] */
+    uint32_t pair_tiles_max;    /* tiles of the longest chain before the next tile length is taken   MM_PAIR_TILES      [40] */
+    uint32_t pair_tile_fixed;   /* 1: every batch with the longest tile length                        MM_PAIR_TILE=max   [0]  */
+    uint32_t pair_xcd;          /* 1: kp_round's workgroups mapped chain by chain onto the XCDs       MM_PAIR_XCD        [1]  */
+    uint32_t pair_group_min;    /* tiles from which a batch runs with the second route level (0: never) MM_PAIR_GROUP    [64] */
+    uint32_t pair_nxseg;        /* anchors per workgroup of kp_nx_init, a power of two in 64..2048 (0: by pool size) MM_PAIR_NXSEG [0] */
+    uint32_t pair_nxstage;      /* entries kp_nx_init stages in LDS (0: all it has room for)          MM_PAIR_NXSTAGE    [0]  */
+    uint32_t pair_tune;         /* PairParams.tune: diagnostic bits (mm_pair.inc)                     MM_PAIR_TUNE       [0]  */
+    /* team path (mm_team.inc) */
+    uint32_t team_batch;        /* passes launched per look of the host at the chains, 1..4096        MM_TEAM_BATCH      [16] */
+    uint32_t team_f2;           /* passes of a tick that compose F with itself (0: none)              MM_TEAM_F2         [32] */
+    uint32_t team_rebuild;      /* the role sub-queues are rebuilt every this many passes, 1..4096    MM_TEAM_REBUILD    [8]  */
+    uint32_t team_emit_max;     /* emitter workgroups per chain and launch, 1..32                     MM_TEAM_EMIT_MAX   [32] */
+    uint32_t team_split;        /* 1: the stored lobby's fill rides in kt_f's launch (passes with kt_f2) MM_TEAM_SPLIT    [1]  */
+    uint32_t team_fwait;        /* polls a chaser waits for a chunk's flag before it looks itself     MM_TEAM_FWAIT      [16384] */
+    uint32_t team_fix_max;      /* replacements per chunk above which it looks everything up again    MM_TEAM_FIXMAX     [0xFFFFFFFF] */
+    uint32_t team_fix_t8;       /* replacements per wave above which a task gets 8 lanes, not 16      MM_TEAM_FIXT8      [10] */
+    uint32_t team_fix_t4;       /* ... above which it gets 4                                          MM_TEAM_FIXT4      [64] */
+    uint32_t team_pull_xcd;     /* 1: emitter workgroups on the chaser's XCD pull F through its L2    MM_TEAM_PULLX      [1]  */
+    uint32_t team_nowait;       /* test hook: the flag of every n-th chunk never comes (0: off)       MM_TEAM_NOWAIT     [0]  */
+    uint32_t team_late;         /* lobbies per pass at or under which kt_late takes over (0: never)   MM_TEAM_LATE       [6]  */
+    uint32_t team_late0;        /* arrivals since a mode's last tick at or under which kt_late walks the tick from its first pass (0: never) MM_TEAM_LATE0 [512] */
+    uint32_t team_cap;          /* sub-queue entries one thread of kt_f looks at per role, 1..4096    MM_TEAM_CAP        [512] */
+} mm_tuning;
+
+/* Fills *t (t->size = the caller's sizeof on entry) with the defaults: the built-in values in [brackets] above, each
+ * overridden by its MM_* environment variable when that is set to a value inside the field's range (a value outside it,
+ * or one that does not parse, is reported on stderr once per create and ignored — until round 5 it was silently a no-op). */
+int mm_tuning_default(mm_tuning* t);
+/* Sets one field by its name as spelled above.  MM_ERR_INVALID_ARG: no such field (or it lies beyond t->size);
+ * MM_ERR_RANGE: the value is outside the field's range.  *t is untouched on error. */
+int mm_tuning_set(mm_tuning* t, const char* name, uint32_t value);
+/* The name of field number `index` (0 = the first after `size`), NULL past the last: lets a binding enumerate. */
+const char* mm_tuning_name(uint32_t index);
+/* mm_engine_create with a tuning record (NULL: mm_tuning_default's).  MM_ERR_RANGE for a field outside its range. */
+int mm_engine_create_ex(const mm_config* cfg, const mm_tuning* tuning, mm_engine** out);
+/* What the engine runs with (t->size in: the caller's sizeof; out: bytes filled). */
+int mm_tuning_get(const mm_engine* e, mm_tuning* t);
+
 /* Drops every queued player and open lobby (a fresh Mnesia + empty broker queues). */
 int mm_reset(mm_engine* e);
 

@@ -108,7 +108,8 @@ ABI_FUNCTIONS = [
     "tick", "matches", "queue_depth", "queue_slots", "lobby_state",
 ]
 PRODUCT_ONLY_FUNCTIONS = ["abi_version", "strerror", "config_default", "enqueue_device",
-                          "last_hip_error", "path_stats_get"]
+                          "last_hip_error", "path_stats_get", "engine_create_ex", "tuning_default", "tuning_set",
+                          "tuning_name", "tuning_get"]
 
 
 class MMCodecCfg(C.Structure):
@@ -232,10 +233,66 @@ class EngineBase:
     _lib = None
     _prefix = "mm_"
 
-    def __init__(self, cfg: MMConfig):
+    def __init__(self, cfg: MMConfig, tuning=None):
+        """tuning: {field of include/mm_engine.h's mm_tuning: value} for THIS engine (mm_engine_create_ex); fields
+        not named keep their defaults (built-in, or the MM_* environment variable's).  Results never depend on it."""
         self.cfg = cfg
         self._h = C.c_void_p()
-        self._check(self._fn("engine_create")(C.byref(cfg), C.byref(self._h)), "engine_create")
+        if tuning:
+            rec = self.tuning_record(tuning)
+            fn = self._fn("engine_create_ex")
+            fn.argtypes = [C.POINTER(MMConfig), C.c_void_p, C.POINTER(C.c_void_p)]
+            fn.restype = C.c_int
+            self._check(fn(C.byref(cfg), rec, C.byref(self._h)), "engine_create_ex")
+        else:
+            self._check(self._fn("engine_create")(C.byref(cfg), C.byref(self._h)), "engine_create")
+
+    # mm_tuning: addressed by NAME through the library (no mirror of the layout here) --------------
+    TUNING_WORDS = 128                        # room for the record of any library version (it fills what it knows)
+
+    @classmethod
+    def tuning_record(cls, tuning=None):
+        """A buffer holding mm_tuning_default() with `tuning` laid over it by mm_tuning_set."""
+        lib, pre = cls._lib, cls._prefix
+        rec = (C.c_uint32 * cls.TUNING_WORDS)()
+        rec[0] = 4 * cls.TUNING_WORDS
+        dflt, setf = getattr(lib, pre + "tuning_default"), getattr(lib, pre + "tuning_set")
+        dflt.argtypes, dflt.restype = [C.c_void_p], C.c_int
+        setf.argtypes, setf.restype = [C.c_void_p, C.c_char_p, C.c_uint32], C.c_int
+        rc = dflt(rec)
+        if rc != 0:
+            raise MMError(rc, pre + "tuning_default")
+        for k, v in (tuning or {}).items():
+            rc = setf(rec, k.encode(), int(v))
+            if rc != 0:
+                raise MMError(rc, "%stuning_set(%s=%r)" % (pre, k, v))
+        return rec
+
+    @classmethod
+    def tuning_names(cls):
+        """The fields of mm_tuning, in order (mm_tuning_name)."""
+        fn = getattr(cls._lib, cls._prefix + "tuning_name")
+        fn.argtypes, fn.restype = [C.c_uint32], C.c_char_p
+        out = []
+        while True:
+            nm = fn(len(out))
+            if nm is None:
+                return out
+            out.append(nm.decode())
+
+    @classmethod
+    def tuning_defaults(cls):
+        rec = cls.tuning_record()
+        return {n: int(rec[1 + i]) for i, n in enumerate(cls.tuning_names())}
+
+    def tuning(self):
+        """mm_tuning_get: what this engine runs with."""
+        fn = self._fn("tuning_get")
+        fn.argtypes, fn.restype = [C.c_void_p, C.c_void_p], C.c_int
+        rec = (C.c_uint32 * self.TUNING_WORDS)()
+        rec[0] = 4 * self.TUNING_WORDS
+        self._check(fn(self._h, rec), "tuning_get")
+        return {n: int(rec[1 + i]) for i, n in enumerate(self.tuning_names())}
 
     # plumbing ------------------------------------------------------------------------
     def _fn(self, name):

@@ -986,7 +986,6 @@ struct mm_engine {
     uint16_t* d_pk_exa[2];
     uint32_t* d_pk_bitsp[2];
     uint32_t* d_pk_headp[2];
-    bool pair_fused;           // MM_PAIR_FUSED=0: three launches per round instead of one (A/B testing)
     bool pair_persist;         // MM_PAIR_PERSIST=0: never several passes per launch (kp_rounds); one launch per pass as before (A/B)
     uint32_t pair_ptiles;      // MM_PAIR_PTILES: tiles of the longest chain a kp_rounds batch may have (one workgroup per CU of ONE XCD: 32)
     uint32_t pair_pcool;       // batches for which kp_rounds stays off after a launch that gave up (a time-out: somebody else holds the CUs)
@@ -1011,6 +1010,7 @@ struct mm_engine {
     bool look_poll;            // MM_LOOK_POLL=0: looks as a D2H copy + stream synchronisation, as before (A/B)
     uint32_t ps_hand[4][MM_MAX_GROUPS];   // per rating group at the pair path's last look: passes, lobbies, kp_rounds passes, kp_rounds hops
     mm_path_stats ps;          // mm_path_stats_get: the launch shapes and fall-backs of the last tick (totals carried over)
+    mm_tuning tn;              // the record the engine was created with (mm_tuning_get); the working copies are the fields around here
     uint32_t team_fwait, team_fix_max, team_fix_t8, team_fix_t4, team_pull_xcd, team_nowait;   // MM_TEAM_* knobs of kt_f / kt_fc, read once at create
     uint32_t pk_bits_stride, pk_max_tiles, pk_stride;
     uint32_t pair_batch;       // MM_PAIR_BATCH: tiled rounds launched per host look at the chains
@@ -1033,7 +1033,6 @@ struct mm_engine {
     uint32_t team_seq;         // kt_chase / kt_fc launches of this engine so far (never 0: it names a launch to its workgroups)
     uint32_t team_emit_max;    // MM_TEAM_EMIT_MAX
     uint32_t team_split;       // MM_TEAM_SPLIT: the stored lobby's fill in kt_f's launch (the lobby-rich passes)
-    bool team_live;            // MM_TEAM_LIVE: kt_f and the chase of a pass in one launch (kt_fc) where there is no kt_f2
     uint32_t* d_tk_sqi;        // [group][pk_stride] position -> sub-queue entry
     uint32_t team_rebuild;     // MM_TEAM_REBUILD: kt_build runs in the first two passes of a tick and every this many after
     uint32_t tk_memb;          // largest lobby of a team mode, less the anchor
@@ -1042,7 +1041,6 @@ struct mm_engine {
     uint32_t team_batch;       // MM_TEAM_BATCH: passes launched per host look at the chains
     uint32_t team_cap;         // MM_TEAM_CAP: TeamParams.scan_cap
     uint32_t team_late;        // MM_TEAM_LATE: lobbies per pass at or under which kt_late takes the chains over (0 = never)
-    bool team_fused;           // MM_TEAM_FUSED: the emitter workgroups ride in kt_chase's launch (mm_team.inc)
     uint32_t team_late0;       // MM_TEAM_LATE0: arrivals of a mode since its last tick at or under which kt_late walks the tick from its first pass
     std::vector<uint32_t> tk_last_len;   // [chain] queue + stored lobby after the chain's last tick (what a quiescent tick left)
     uint32_t dbg_last_w, dbg_last_c;   // MM_PAIR_DEBUG + MM_TEAM_BATCH=1: per-pass deltas of the F counters
@@ -1364,13 +1362,133 @@ static int engine_reset_device(mm_engine* e)
     return MM_OK;
 }
 
-extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
+// ---- mm_tuning (include/mm_engine.h): the table of fields, their environment defaults and ranges ----
+struct TuneDesc { const char* name; const char* env; uint32_t off, def, lo, hi, kind; };   // kind 1: zero or a power of two in [lo, hi]
+#define MM_TD(f, envname, def, lo, hi, kind) { #f, envname, (uint32_t)offsetof(mm_tuning, f), def, lo, hi, kind }
+static const TuneDesc k_tune[] = {
+    MM_TD(force_generic, "MM_FORCE_GENERIC", 0u, 0u, 1u, 0u),
+    MM_TD(debug, "MM_PAIR_DEBUG", 0u, 0u, 1u, 0u),
+    MM_TD(results_early, "MM_RESULTS_EARLY", 1u, 0u, 1u, 0u),
+    MM_TD(results_tail, "MM_RESULTS_TAIL", 1u, 0u, 1u, 0u),
+    MM_TD(look_poll, "MM_LOOK_POLL", 0u, 0u, 1u, 0u),
+    MM_TD(fail_tick, "MM_DEBUG_FAIL_TICK", 0u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(pair_persist, "MM_PAIR_PERSIST", 1u, 0u, 1u, 0u),
+    MM_TD(pair_ptiles, "MM_PAIR_PTILES", 32u, 1u, 32u, 0u),
+    MM_TD(pair_pbatch, "MM_PAIR_PBATCH", 48u, 1u, 4096u, 0u),
+    MM_TD(pair_batch, "MM_PAIR_BATCH", 48u, 1u, 4096u, 0u),
+    MM_TD(pair_ptimeout_us, "MM_PAIR_PTIMEOUT_US", 5000u, 0u, 1000000u, 0u),
+    MM_TD(pair_pinject, "MM_PAIR_PINJECT", 0u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(pair_tiles_max, "MM_PAIR_TILES", PK_TILES_MAX, 1u, 4096u, 0u),
+    MM_TD(pair_tile_fixed, "MM_PAIR_TILE", 0u, 0u, 1u, 0u),
+    MM_TD(pair_xcd, "MM_PAIR_XCD", 1u, 0u, 1u, 0u),
+    MM_TD(pair_group_min, "MM_PAIR_GROUP", PK_GROUP_MIN, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(pair_nxseg, "MM_PAIR_NXSEG", 0u, 64u, NXI_SEG, 1u),
+    MM_TD(pair_nxstage, "MM_PAIR_NXSTAGE", 0u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(pair_tune, "MM_PAIR_TUNE", 0u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_batch, "MM_TEAM_BATCH", 16u, 1u, 4096u, 0u),
+    MM_TD(team_f2, "MM_TEAM_F2", 32u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_rebuild, "MM_TEAM_REBUILD", 8u, 1u, 4096u, 0u),
+    MM_TD(team_emit_max, "MM_TEAM_EMIT_MAX", TC_EMIT_MAX, 1u, TC_EMIT_MAX, 0u),
+    MM_TD(team_split, "MM_TEAM_SPLIT", 1u, 0u, 1u, 0u),
+    MM_TD(team_fwait, "MM_TEAM_FWAIT", 1u << 14, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_fix_max, "MM_TEAM_FIXMAX", 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_fix_t8, "MM_TEAM_FIXT8", 10u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_fix_t4, "MM_TEAM_FIXT4", 64u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_pull_xcd, "MM_TEAM_PULLX", 1u, 0u, 1u, 0u),
+    MM_TD(team_nowait, "MM_TEAM_NOWAIT", 0u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_late, "MM_TEAM_LATE", 6u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_late0, "MM_TEAM_LATE0", 512u, 0u, 0xFFFFFFFFu, 0u),
+    MM_TD(team_cap, "MM_TEAM_CAP", TT_SCAN_CAP, 1u, 4096u, 0u),
+};
+#undef MM_TD
+static const uint32_t k_tune_n = (uint32_t)(sizeof(k_tune) / sizeof(k_tune[0]));
+static_assert(sizeof(mm_tuning) == (sizeof(k_tune) / sizeof(k_tune[0]) + 1u) * sizeof(uint32_t), "every field of mm_tuning has its row in k_tune");
+
+static bool tune_in_range(const TuneDesc& d, uint32_t v)
+{
+    if (d.kind == 1u) return v == 0u || (v >= d.lo && v <= d.hi && (v & (v - 1u)) == 0u);
+    return v >= d.lo && v <= d.hi;
+}
+static uint32_t& tune_field(mm_tuning* t, const TuneDesc& d) { return *(uint32_t*)((char*)t + d.off); }
+
+// the defaults: built-in values, each overridden by its environment variable when that parses and is in range
+static void tune_defaults(mm_tuning* full)
+{
+    full->size = (uint32_t)sizeof(mm_tuning);
+    for (uint32_t i = 0; i < k_tune_n; ++i) {
+        const TuneDesc& d = k_tune[i];
+        uint32_t v = d.def;
+        const char* s = getenv(d.env);
+        if (s && *s) {
+            char* end = NULL;
+            unsigned long long x = strtoull(s, &end, 0);
+            bool ok = end && *end == 0 && end != s && x <= 0xFFFFFFFFull;
+            if (!ok && d.off == (uint32_t)offsetof(mm_tuning, pair_tile_fixed) && (s[0] == 'm' || s[0] == 'M')) { x = 1u; ok = true; }   // MM_PAIR_TILE=max
+            if (ok && tune_in_range(d, (uint32_t)x)) v = (uint32_t)x;
+            else fprintf(stderr, "[mm-engine] %s=%s is not a value of mm_tuning.%s: ignored, %u stays\n", d.env, s, d.name, v);
+        }
+        tune_field(full, d) = v;
+    }
+}
+
+extern "C" int mm_tuning_default(mm_tuning* t)
+{
+    if (!t || t->size < sizeof(uint32_t)) return MM_ERR_INVALID_ARG;
+    mm_tuning full;
+    tune_defaults(&full);
+    const uint32_t n = t->size < (uint32_t)sizeof(full) ? t->size & ~3u : (uint32_t)sizeof(full);
+    full.size = n;
+    memcpy(t, &full, n);
+    return MM_OK;
+}
+
+extern "C" int mm_tuning_set(mm_tuning* t, const char* name, uint32_t value)
+{
+    if (!t || !name) return MM_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < k_tune_n; ++i) {
+        const TuneDesc& d = k_tune[i];
+        if (strcmp(d.name, name) != 0) continue;
+        if (d.off + sizeof(uint32_t) > t->size) return MM_ERR_INVALID_ARG;
+        if (!tune_in_range(d, value)) return MM_ERR_RANGE;
+        tune_field(t, d) = value;
+        return MM_OK;
+    }
+    return MM_ERR_INVALID_ARG;
+}
+
+extern "C" const char* mm_tuning_name(uint32_t index) { return index < k_tune_n ? k_tune[index].name : NULL; }
+
+extern "C" int mm_tuning_get(const mm_engine* e, mm_tuning* t)
+{
+    if (!e || !t || t->size < sizeof(uint32_t)) return MM_ERR_INVALID_ARG;
+    mm_tuning full = e->tn;
+    const uint32_t n = t->size < (uint32_t)sizeof(full) ? t->size & ~3u : (uint32_t)sizeof(full);
+    full.size = n;
+    memcpy(t, &full, n);
+    return MM_OK;
+}
+
+extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out) { return mm_engine_create_ex(cfg, NULL, out); }
+
+extern "C" int mm_engine_create_ex(const mm_config* cfg, const mm_tuning* tuning, mm_engine** out)
 {
     try {
         if (!cfg || !out) return MM_ERR_INVALID_ARG;
         *out = NULL;
         int rc = cfg_validate(cfg);
         if (rc) return rc;
+        mm_tuning tn;
+        tune_defaults(&tn);
+        if (tuning) {
+            if (tuning->size < sizeof(uint32_t)) return MM_ERR_INVALID_ARG;
+            for (uint32_t i = 0; i < k_tune_n; ++i) {
+                const TuneDesc& d = k_tune[i];
+                if (d.off + sizeof(uint32_t) > tuning->size) continue;        // a shorter record of an older caller: the default stays
+                const uint32_t v = *(const uint32_t*)((const char*)tuning + d.off);
+                if (!tune_in_range(d, v)) return MM_ERR_RANGE;
+                tune_field(&tn, d) = v;
+            }
+        }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
             return MM_ERR_NO_DEVICE;
@@ -1378,6 +1496,7 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         mm_engine* e = new (std::nothrow) mm_engine();
         if (!e) return MM_ERR_OOM;
         e->cfg = *cfg;
+        e->tn = tn;
         e->n_chains = cfg->n_modes * cfg->n_groups;
         e->last_hip = 0;
         e->next_slot = 0;
@@ -1390,97 +1509,61 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         e->poisoned = false;
         e->ticks_seen = 0;
         {
-            const char* ft = getenv("MM_DEBUG_FAIL_TICK");
-            e->fault_tick = ft ? (uint32_t)strtoul(ft, NULL, 0) : 0u;
-            const char* fg = getenv("MM_FORCE_GENERIC");
-            e->force_generic = fg && fg[0] == '1';
-            const char* pd = getenv("MM_PAIR_DEBUG");
-            e->pair_debug = pd && pd[0] == '1';
-            const char* pt = getenv("MM_PAIR_TUNE");
-            e->pair_tune = pt ? (uint32_t)strtoul(pt, NULL, 0) : 0u;
-            const char* ptl = getenv("MM_PAIR_TILE");
-            e->pair_tile_fixed = ptl && ptl[0] == 'm';
-            const char* ptm = getenv("MM_PAIR_TILES");
-            e->pair_tiles_max = ptm && atoi(ptm) > 0 ? (uint32_t)atoi(ptm) : PK_TILES_MAX;
-            const char* pxc = getenv("MM_PAIR_XCD");
-            e->pair_xcd = !(pxc && pxc[0] == '0');
-            const char* pgm = getenv("MM_PAIR_GROUP");
-            e->pair_group_min = pgm ? (uint32_t)strtoul(pgm, NULL, 0) : PK_GROUP_MIN;
-            const char* pf = getenv("MM_PAIR_FUSED");
-            e->pair_fused = !(pf && pf[0] == '0');
+            // the tuning record (include/mm_engine.h, mm_tuning): validated by the caller below; the engine keeps it (mm_tuning_get)
+            // and its working copies — some of which change while it runs (pair_persist after a PF_XCD stop)
+            const mm_tuning& t = e->tn;
+            e->fault_tick = t.fail_tick;
+            e->force_generic = t.force_generic != 0u;
+            e->pair_debug = t.debug != 0u;
+            e->pair_tune = t.pair_tune;
+            e->pair_tile_fixed = t.pair_tile_fixed != 0u;
+            e->pair_tiles_max = t.pair_tiles_max;
+            e->pair_xcd = t.pair_xcd != 0u;
+            e->pair_group_min = t.pair_group_min;
             e->round_ctr = 0;
-            const char* pp = getenv("MM_PAIR_PERSIST");
-            e->pair_persist = !(pp && pp[0] == '0');
-            const char* ppt = getenv("MM_PAIR_PTILES");
-            e->pair_ptiles = ppt && atoi(ppt) > 0 ? (uint32_t)atoi(ppt) : 32u;
-            if (e->pair_ptiles > 32u) e->pair_ptiles = 32u;
-            const char* ppi = getenv("MM_PAIR_PINJECT");
-            e->pair_pinject = ppi ? (uint32_t)strtoul(ppi, NULL, 0) : 0u;
-            const char* pto = getenv("MM_PAIR_PTIMEOUT_US");
+            e->pair_persist = t.pair_persist != 0u;
+            e->pair_ptiles = t.pair_ptiles;
+            e->pair_pinject = t.pair_pinject;
             // the first barrier of a launch is where a workgroup that found no CU is waited for (another engine's launch in the
             // way ends within a millisecond or two); behind it everybody is on the chip and only slow, never absent
             // — 5 ms, half a tick period of the stream (20 ms until round 5: two whole periods of spinning whenever somebody
-            // else held the CUs, and kp_round is a cheap way on); 200 ms behind it, as before
-            e->pair_ptimeout[0] = (pto ? (uint32_t)strtoul(pto, NULL, 0) : 5000u) * 100u;
+            // else held the CUs, and kp_round is a cheap way on); 40 x that behind it (200 ms), as before.  In 100 MHz ticks.
+            e->pair_ptimeout[0] = t.pair_ptimeout_us * 100u;
             e->pair_ptimeout[1] = e->pair_ptimeout[0] * 40u;
             e->pair_pcool = 0;
             e->pair_pstops = 0;
-            { const char* nxs = getenv("MM_PAIR_NXSEG"); e->pair_nxseg = nxs ? (uint32_t)strtoul(nxs, NULL, 0) : 0u;
-              if (e->pair_nxseg && (e->pair_nxseg < 64u || e->pair_nxseg > NXI_SEG)) e->pair_nxseg = 0u;
-              const char* nxt = getenv("MM_PAIR_NXSTAGE"); e->pair_nxstage = nxt ? (uint32_t)strtoul(nxt, NULL, 0) : 0u; }
-            const char* ppb = getenv("MM_PAIR_PBATCH");
-            e->pair_pbatch = ppb && atoi(ppb) > 0 ? (uint32_t)atoi(ppb) : 48u;       // 48 / 64 / 96 measured: 95.7 / 94.6 / 93.5 M matched players/s (gpurun_out/ab_r4f.jsonl)
-            const char* pb = getenv("MM_PAIR_BATCH");
-            e->pair_batch = pb ? (uint32_t)strtoul(pb, NULL, 0) : 48u;   // 16 / 32 / 48 / 64 measured: 48 by 1-2 %
-            if (e->pair_batch < 1u) e->pair_batch = 1u;
-            const char* tb = getenv("MM_TEAM_BATCH");
-            e->team_batch = tb ? (uint32_t)strtoul(tb, NULL, 0) : 16u;
-            if (e->team_batch < 1u) e->team_batch = 1u;
-            const char* tf2 = getenv("MM_TEAM_F2");
-            e->team_f2 = tf2 ? (uint32_t)strtoul(tf2, NULL, 0) : 32u;   // 24 / 40 measured within 0.1 ms of each other
-            const char* trb = getenv("MM_TEAM_REBUILD");
-            e->team_rebuild = trb ? (uint32_t)strtoul(trb, NULL, 0) : 8u;   // 4 / 6 / 8 measured within 0.1 ms of each other, 16: +0.9 ms, every pass: +1.4 ms
-            if (e->team_rebuild < 1u) e->team_rebuild = 1u;
-            const char* tfe = getenv("MM_TEAM_FUSED");
-            e->team_fused = !(tfe && tfe[0] == '0');                     // 0: kt_emit as a launch of its own behind every chase (cfg-3: +1.3 ms per tick)
-            const char* tem = getenv("MM_TEAM_EMIT_MAX");
-            e->team_emit_max = tem ? (uint32_t)strtoul(tem, NULL, 0) : TC_EMIT_MAX;   // emitter workgroups per chain and launch at most
-            if (e->team_emit_max > TC_EMIT_MAX) e->team_emit_max = TC_EMIT_MAX;       // (kt_pack resets vis[] for this many workers: TV_AHEAD)
-            { const char* tsp = getenv("MM_TEAM_SPLIT"); e->team_split = tsp ? (uint32_t)strtoul(tsp, NULL, 0) : 1u; }
-            {   // (read here, once: getenv on the tick's path is neither cheap nor safe beside a setenv of the host process)
-                const char* fw = getenv("MM_TEAM_FWAIT");
-                e->team_fwait = fw ? (uint32_t)strtoul(fw, NULL, 0) : (1u << 14);       // ~5 ms of polls, then the chaser helps itself
-                const char* fm = getenv("MM_TEAM_FIXMAX");
-                e->team_fix_max = fm ? (uint32_t)strtoul(fm, NULL, 0) : 0xFFFFFFFFu;   // (measured: mending always wins once a task is a quarter wave's)
-                const char* f8 = getenv("MM_TEAM_FIXT8");
-                const char* f4 = getenv("MM_TEAM_FIXT4");
-                e->team_fix_t8 = f8 ? (uint32_t)strtoul(f8, NULL, 0) : 10u;
-                e->team_fix_t4 = f4 ? (uint32_t)strtoul(f4, NULL, 0) : 64u;
-                const char* px = getenv("MM_TEAM_PULLX");
-                e->team_pull_xcd = px ? (uint32_t)strtoul(px, NULL, 0) : 1u;
-                const char* nw = getenv("MM_TEAM_NOWAIT");
-                e->team_nowait = nw ? (uint32_t)strtoul(nw, NULL, 0) : 0u;
-                memset(&e->ps, 0, sizeof(e->ps));
-                e->ps.mode = 0xFFFFFFFFu;
-            }
-            if (e->team_emit_max < 1u) e->team_emit_max = 1u;
-            const char* tlv = getenv("MM_TEAM_LIVE");
-            e->team_live = !(tlv && tlv[0] == '0');                      // 0: kt_f and kt_chase as launches of their own in every pass (cfg-3: +0.7 ms per tick)
+            e->pair_nxseg = t.pair_nxseg;
+            e->pair_nxstage = t.pair_nxstage;
+            e->pair_pbatch = t.pair_pbatch;       // 48 / 64 / 96 measured: 95.7 / 94.6 / 93.5 M matched players/s (round 4)
+            e->pair_batch = t.pair_batch;         // 16 / 32 / 48 / 64 measured: 48 by 1-2 %
+            e->team_batch = t.team_batch;
+            e->team_f2 = t.team_f2;               // 24 / 40 measured within 0.1 ms of each other
+            e->team_rebuild = t.team_rebuild;     // 4 / 6 / 8 measured within 0.1 ms of each other, 16: +0.9 ms, every pass: +1.4 ms
+            e->team_emit_max = t.team_emit_max;   // emitter workgroups per chain and launch at most (kt_pack resets vis[] for this many workers: TV_AHEAD)
+            e->team_split = t.team_split;
+            e->team_fwait = t.team_fwait;         // ~5 ms of polls, then the chaser helps itself
+            e->team_fix_max = t.team_fix_max;     // (measured: mending always wins once a task is a quarter wave's)
+            e->team_fix_t8 = t.team_fix_t8;
+            e->team_fix_t4 = t.team_fix_t4;
+            e->team_pull_xcd = t.team_pull_xcd;
+            e->team_nowait = t.team_nowait;
+            memset(&e->ps, 0, sizeof(e->ps));
+            e->ps.mode = 0xFFFFFFFFu;
             e->team_seq = 0;
-            const char* tl0 = getenv("MM_TEAM_LATE0");
-            e->team_late0 = tl0 ? (uint32_t)strtoul(tl0, NULL, 0) : 512u;
+            e->team_late0 = t.team_late0;
             e->tk_last_len.assign(e->n_chains, 0u);
-            const char* rse = getenv("MM_RESULTS_EARLY");
-            e->results_early = !(rse && rse[0] == '0');
-            const char* tlt = getenv("MM_TEAM_LATE");
+            e->results_early = t.results_early != 0u;
             // measured on cfg-3 (profiles/r03_ab_team_late.txt): 0: 12.99 ms, 3: 12.50, 6: 12.46, 12: 12.76, 20: 13.67, 40: 15.73 per tick,
             // and again with one launch per pass (kt_fc): 0: 10.9, 6: 9.89, 12: 10.01, 20: 10.6 — a look-up costs the chaser ~4 us
             // (dependent trips to memory at ~1.2 us each), so it only beats a pass kernel while a pass seats a handful of lobbies
-            e->team_late = tlt ? (uint32_t)strtoul(tlt, NULL, 0) : 6u;
-            const char* tcap = getenv("MM_TEAM_CAP");
-            e->team_cap = tcap ? (uint32_t)strtoul(tcap, NULL, 0) : TT_SCAN_CAP;
-            if (e->team_cap < 1u) e->team_cap = 1u;
-            if (e->team_cap > 4096u) e->team_cap = 4096u;      // kt_f notes members as 13-bit sub-queue offsets (TF_REL_BITS)
+            e->team_late = t.team_late;
+            e->team_cap = t.team_cap;             // <= 4096: kt_f notes members as 13-bit sub-queue offsets (TF_REL_BITS)
+            // look_poll OFF by default.  Measured (profiles/r05_ab_look_poll.txt, cfg-2 / cfg-3, 40 steps, twice each on one box): the
+            // median step gains 0.03 ms of 10.1 (1v1) and 0.05 ms of 8.5 (5v5) — the copy + synchronisation of a look is NOT where a
+            // tick's time goes — and every polled 1v1 run had ONE step of 17 ms: a host thread that spins for the whole tick is what a
+            // container's CPU quota throttles first (a dirty scheduler of the BEAM would fare no better).
+            e->look_poll = t.look_poll != 0u;
+            e->results_tail_kernel = t.results_tail != 0u;
         }
         const size_t cap = cfg->capacity;
     #define CREATE_CHK(call)                                                 \
@@ -1580,12 +1663,6 @@ extern "C" int mm_engine_create(const mm_config* cfg, mm_engine** out)
         CREATE_CHK(hipHostMalloc((void**)&e->h_look_seq, 64, hipHostMallocDefault));
         *e->h_look_seq = 0;
         e->look_seq = 0;
-        // OFF by default.  Measured (profiles/r05_ab_look_poll.txt, cfg-2 / cfg-3, 40 steps, twice each on one box): the median
-        // step gains 0.03 ms of 10.1 (1v1) and 0.05 ms of 8.5 (5v5) — the copy + synchronisation of a look is NOT where a tick's
-        // time goes — and every polled 1v1 run had ONE step of 17 ms: a host thread that spins for the whole tick is what a
-        // container's CPU quota throttles first (a dirty scheduler of the BEAM would fare no better).  MM_LOOK_POLL=1 for A/B.
-        { const char* lp = getenv("MM_LOOK_POLL"); e->look_poll = lp && lp[0] == '1'; }
-        { const char* rt = getenv("MM_RESULTS_TAIL"); e->results_tail_kernel = !(rt && rt[0] == '0'); }
         CREATE_CHK(hipHostMalloc((void**)&e->h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault));
         e->h_state.assign(cap, MM_ST_FREE);
         if (e->tk_memb) {
@@ -2123,12 +2200,16 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
         if (tiles > e->pk_max_tiles) tiles = e->pk_max_tiles;
         bool after_persist = false;            // the look directly behind a kp_rounds launch: only there is PairChain.pfail news
         uint32_t last_tp = 0;                  // the tile length of the tick's last batch (it never grows: below)
+        uint32_t idle_looks = 0;               // looks in a row at which no tiled chain had retired a pass or left the tiled stage
+        unsigned long long last_progress = ~0ull;
         for (uint32_t guard = 0;; ++guard) {
-            // A pass without a change ends a chain, so a chain has at most `capacity` passes; an iteration retires at least one
-            // pass of every tiled chain, or is one of the few kinds that retire none and are each followed by one that does
-            // (a compaction-only look; a kp_rounds launch that stopped at its first barrier, after which kp_rounds stays off
-            // for 16 batches): three iterations per pass are an upper bound (never reached in practice)
-            if (guard > 3u * cfg.capacity + 64u) return MM_ERR_INTERNAL;
+            // A pass without a change ends a chain, so a tick is finite; an iteration (a look + a batch) retires at least one pass
+            // of every tiled chain, or is one of the few kinds that retire none and are each followed by one that does (a
+            // compaction-only look; a kp_rounds launch that stopped at its first barrier, after which kp_rounds stays off for
+            // 16 batches).  The watchdog counts the looks in a row at which nothing had moved.
+            // counted in looks that bound was 3 x capacity round trips (tens of minutes at 2^24 before MM_ERR_INTERNAL,
+            // and 3u * capacity wraps above 1.43e9).  Counted in PASSES it is tight: see idle_looks below.
+            if (idle_looks > 64u) return MM_ERR_INTERNAL;
             { int lrc = look_launch(e, e->d_pchains, e->h_pchains, G * sizeof(PairChain)); if (lrc) return lrc; }
             { int lrc = look_wait(e); if (lrc) return lrc; }
             ++e->ps.host_looks;
@@ -2139,6 +2220,16 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                     if (pc.fast) fprintf(stderr, " g%u[stage %u m %u qlen %u passes %u compact %u pfail 0x%x]", g, pc.stage, pc.m, pc.qlen, pc.passes, pc.want_compact, pc.pfail);
                 }
                 fprintf(stderr, "\n");
+            }
+            {   // the watchdog: passes retired + chains still tiled + compactions done must move; the looks that move nothing (a
+                // compaction-only look, a kp_rounds launch that stopped at its first barrier) are each followed by one that does
+                unsigned long long progress = 0;
+                for (uint32_t g = 0; g < G; ++g) {
+                    const PairChain& pc = e->h_pchains[g];
+                    if (pc.fast) progress += (unsigned long long)pc.passes + ((unsigned long long)pc.m << 32) + (pc.stage == PS_TILED ? 1u : 0u) + pc.want_compact;
+                }
+                idle_looks = progress == last_progress ? idle_looks + 1u : 0u;
+                last_progress = progress;
             }
             bool tiled = false, compact = false;
             uint32_t longest = 0;
@@ -2202,7 +2293,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             // compacted now rather than at 75 % alive.  Only the longest chain decides the tile length.
             bool want_fit = false;
             uint32_t yield_q = 0, yield_g = 0;
-            if (e->pair_fused && e->pair_persist && !e->pair_pcool && !compact && !e->pair_tile_fixed) {
+            if (e->pair_persist && !e->pair_pcool && !compact && !e->pair_tile_fixed) {
                 uint32_t gl = 0;
                 for (uint32_t g = 1; g < G; ++g)
                     if (P.bm[g] > P.bm[gl]) gl = g;
@@ -2223,14 +2314,13 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 }
             }
             // tile length of this batch: the smallest that keeps the longest chain within PK_TILES_MAX tiles (the
-            // walk costs one dependent load per tile, everything else is proportional to the tile); the
-            // three-launch form of a round (MM_PAIR_FUSED=0) stays with the largest
+            // walk costs one dependent load per tile, everything else is proportional to the tile)
             uint32_t tp = PK_TMAX;
             // several passes per launch (kp_rounds) when every chain's tiles fit the CUs of one XCD
-            bool persist = e->pair_fused && e->pair_persist && !compact && (longest + PK_TMAX - 1u) / PK_TMAX <= e->pair_ptiles;
+            bool persist = e->pair_persist && !compact && (longest + PK_TMAX - 1u) / PK_TMAX <= e->pair_ptiles;
             if (persist && e->pair_pcool) { --e->pair_pcool; persist = false; e->ps.degraded = 1; }
             // (a batch that kp_rounds would have taken, walked launch by launch because it is off: a fall-back's timing)
-            if (e->pair_fused && !e->pair_persist && !compact && (longest + PK_TMAX - 1u) / PK_TMAX <= e->pair_ptiles) e->ps.degraded = 1;
+            if (!e->pair_persist && !compact && (longest + PK_TMAX - 1u) / PK_TMAX <= e->pair_ptiles) e->ps.degraded = 1;
             // ONE cap for the tile count whether this batch is kp_rounds' or kp_round's (round 5): the tile length of a tick must
             // never GROW.  An entry next[i] = NX_FAR says "nobody fits inside the horizon", and the horizon is two tiles of the
             // length it was computed at; the walk resolves it by scanning from the end of the CURRENT horizon — right for an
@@ -2241,8 +2331,8 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             // tests/stress.py with MM_PAIR_PTILES=5 (seed 130203984: 46 lobbies of one chain missing), on the device and on
             // the shim; it needs a stop of kp_rounds (or the knob) to happen, which is why no default run ever met it.
             const uint32_t cap_p = e->pair_ptiles < e->pair_tiles_max ? e->pair_ptiles : e->pair_tiles_max;
-            const uint32_t tiles_max = (e->pair_fused && e->pair_persist) ? cap_p : e->pair_tiles_max;
-            if (e->pair_fused && !e->pair_tile_fixed)
+            const uint32_t tiles_max = e->pair_persist ? cap_p : e->pair_tiles_max;
+            if (!e->pair_tile_fixed)
                 for (uint32_t cand = PK_TMAX / 4u; cand < PK_TMAX; cand <<= 1)    // (an eighth was measured: slower, the fixed cost of a round takes over)
                     if ((longest + cand - 1u) / cand <= tiles_max) { tp = cand; break; }
             if (last_tp && tp > last_tp && !compact) {
@@ -2277,7 +2367,7 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
             last_tp = tp;
             for (uint32_t g = 0; g < G; ++g) P.pyq[g] = 0;
             P.pyq[yield_g] = yield_q;
-            if (e->pair_fused) {
+            {
                 // one launch per pass; the first of a batch only prepares, the commit brings the
                 // latest parity back into the chains' committed state
                 // chains of many tiles: a second level of the route, rebuilt behind every round (kp_group)
@@ -2326,12 +2416,6 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 hipLaunchKernelGGL(kp_round_stage, dim3(G), dim3(64), 0, e->stream, P, r);
                 COMPACT_LAUNCH();
                 e->round_ctr = r;
-            } else {
-                for (uint32_t r = 0; r < e->pair_batch; ++r) {
-                    hipLaunchKernelGGL(kp_tile_prep, dim3(tiles, G), dim3(PT_THREADS), 0, e->stream, P);
-                    hipLaunchKernelGGL(kp_route, dim3(G), dim3(PR_THREADS), 0, e->stream, P);
-                    hipLaunchKernelGGL(kp_tile_apply, dim3(tiles, G), dim3(PA_THREADS), 0, e->stream, P);
-                }
             }
 #undef COMPACT_LAUNCH
 #undef TILE_LAUNCH
@@ -2462,8 +2546,6 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
         P.fo_dhi[K] = 0;
     };
     team_order();
-    uint32_t ex = longest / (M.L * TE_WAVES * 2u) + 1u;
-    if (ex > 256u) ex = 256u;
     hipLaunchKernelGGL(kt_pack, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
     // Batches of passes between two looks at the chains.  The first is short (a tick of a stream seats a handful of
@@ -2499,28 +2581,23 @@ static int team_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge, 
                 }
                 force_build = false;
                 // the emitters ride in the chase's launch, enough waves for the lobbies the last look saw per pass (a pass
-                // that emits more than that is only slower); MM_TEAM_FUSED=0: kt_emit as a launch of its own behind it
+                // that emits more than that is only slower)
                 if (++e->team_seq == 0u) e->team_seq = 1u;
                 P.seq = e->team_seq;
-                P.n_emit = e->team_fused ? n_emit : 0u;
+                P.n_emit = n_emit;
                 P.hf_x = 0xFFFFFFFFu;
                 if (P.use_f2) {
                     // (the stored lobbies' fill from the heads of the queues rides in kt_f's launch: MM_TEAM_SPLIT)
                     if (e->team_split) P.hf_x = nch;
                     hipLaunchKernelGGL(kt_f, dim3(nch + (e->team_split ? 1u : 0u), G), dim3(TT_CH), 0, e->stream, P);
                     hipLaunchKernelGGL(kt_f2, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
-                    hipLaunchKernelGGL(kt_chase<1>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
+                    hipLaunchKernelGGL(kt_chase, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
                     ++e->ps.team_f_launches;
-                } else if (e->team_live) {
+                } else {
                     ++e->ps.team_fc_launches;
                     // kt_f and the chase of the pass in one launch: the chasers take F chunk by chunk as it is written
                     hipLaunchKernelGGL(kt_fc, dim3(G * (1u + P.n_emit) + fo_total), dim3(TT_CH), 0, e->stream, P);
-                } else {
-                    hipLaunchKernelGGL(kt_f, dim3(nch, G), dim3(TT_CH), 0, e->stream, P);
-                    hipLaunchKernelGGL(kt_chase<0>, dim3(G * (1u + P.n_emit)), dim3(TC_THREADS), 0, e->stream, P);
-                    ++e->ps.team_f_launches;
                 }
-                if (!e->team_fused) hipLaunchKernelGGL(kt_emit, dim3(ex, G), dim3(64 * TE_WAVES), 0, e->stream, P);
             }
         }
         HIPCHK(e, hipGetLastError());
@@ -2691,8 +2768,6 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
         if (team_any) e->ps.paths |= MM_PATH_TEAM;
     }
     if (!e->ps.paths) e->ps.paths = MM_PATH_GENERIC;        // (k_walk also takes the short chains the other two leave: not recorded)
-    {
-    }
     WalkParams P;
     memset(&P, 0, sizeof(P));
     P.mode = mode;
@@ -2732,15 +2807,10 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
                     hp[g].dbg[2], hp[g].dbg[3], hp[g].dbg[4], hp[g].dbg[5], hp[g].dbg[6], hp[g].dbg[7]);
         for (uint32_t g = 0; g < G; ++g)
             if (hp[g].rounds) {
-                const uint32_t nr = e->pair_fused ? (hp[g].tm[5] ? hp[g].tm[5] : 1u) : hp[g].rounds;
-                if (e->pair_fused)
-                    fprintf(stderr, "[mm-pair] g%u tile1 cycles/round over %u rounds (load %u walk+stage+sweepA %u apply %u | detect %u items %u long %u (%.1f long items) | graph %u resolve %u publish %u | cand+head %u)\n",
-                            g, nr, hp[g].tm[0] / nr, hp[g].tm[6] / nr, hp[g].tm[9] / nr, hp[g].tm[1] / nr, hp[g].tm[12] / nr, hp[g].tm[2] / nr,
-                            (double)hp[g].tm[11] / nr, hp[g].tm[7] / nr, hp[g].tm[8] / nr, hp[g].tm[10] / nr, hp[g].tm[4] / nr);
-                else
-                    fprintf(stderr, "[mm-pair] g%u tile1 cycles/round over %u rounds (load %u route %u apply %u | repair %u build %u resolve %u publish %u)\n",
-                            g, nr, hp[g].tm[0] / nr, hp[g].tm[7] / nr, hp[g].tm[9] / nr,
-                            hp[g].tm[1] / nr, hp[g].tm[2] / nr, hp[g].tm[3] / nr, hp[g].tm[4] / nr);
+                const uint32_t nr = hp[g].tm[5] ? hp[g].tm[5] : 1u;
+                fprintf(stderr, "[mm-pair] g%u tile1 cycles/round over %u rounds (load %u walk+stage+sweepA %u apply %u | detect %u items %u long %u (%.1f long items) | graph %u resolve %u publish %u | cand+head %u)\n",
+                        g, nr, hp[g].tm[0] / nr, hp[g].tm[6] / nr, hp[g].tm[9] / nr, hp[g].tm[1] / nr, hp[g].tm[12] / nr, hp[g].tm[2] / nr,
+                        (double)hp[g].tm[11] / nr, hp[g].tm[7] / nr, hp[g].tm[8] / nr, hp[g].tm[10] / nr, hp[g].tm[4] / nr);
             }
         for (uint32_t g = 0; g < G; ++g)
             if (hp[g].ppass) {
@@ -2869,12 +2939,15 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     e->r_n = total;
     if (n_matches) *n_matches = total;
     if (e->ps.paths & MM_PATH_PAIR) {            // mm_path_stats_get: the chain with the most passes, by launch shape
-        uint32_t gc = 0;
-        for (uint32_t g = 1; g < G; ++g)
-            if (e->h_chains[mode * G + g].passes > e->h_chains[mode * G + gc].passes) gc = g;
-        const ChainDev& cd = e->h_chains[mode * G + gc];
+        // ... among the chains the pair path walked: one k_walk took (PairChain.fast == 0: a rating span beyond the packed key)
+        // has no launch shapes to report, and its passes counted as kp_late's would price them as LDS steps
+        uint32_t gc = 0xFFFFFFFFu;
+        for (uint32_t g = 0; g < G; ++g)
+            if (e->h_pchains[g].fast && (gc == 0xFFFFFFFFu || e->h_chains[mode * G + g].passes > e->h_chains[mode * G + gc].passes)) gc = g;
         e->ps.crit_group = gc;
-        e->ps.crit_passes = cd.passes;
+        if (gc == 0xFFFFFFFFu) gc = 0;            // (none: the zeros of ps_hand say so)
+        const ChainDev& cd = e->h_chains[mode * G + gc];
+        e->ps.crit_passes = e->ps.crit_group == 0xFFFFFFFFu ? 0u : cd.passes;
         e->ps.crit_rounds_passes = e->ps_hand[2][gc];
         e->ps.crit_rounds_hops = e->ps_hand[3][gc];
         e->ps.crit_round_passes = e->ps_hand[0][gc] >= e->ps_hand[2][gc] ? e->ps_hand[0][gc] - e->ps_hand[2][gc] : 0u;

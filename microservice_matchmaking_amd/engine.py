@@ -56,10 +56,10 @@ class Engine(EngineBase):
 
     _prefix = "mm_"
 
-    def __init__(self, cfg: MMConfig):
+    def __init__(self, cfg: MMConfig, tuning=None):
         if Engine._lib is None:
             Engine._lib = load_library()
-        super().__init__(cfg)
+        super().__init__(cfg, tuning)
 
     def enqueue_device(self, d_rating, d_cons):
         """rating/cons are CUDA(HIP) torch tensors (int32 / int32-viewed-uint32) already in

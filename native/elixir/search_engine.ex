@@ -18,6 +18,8 @@ defmodule Matchmaking.Search.Engine do
   def default_config(), do: :erlang.nif_error(:nif_not_loaded)
   def find_rating_group(_config, _rating), do: :erlang.nif_error(:nif_not_loaded)
   def create(_config), do: :erlang.nif_error(:nif_not_loaded)
+  # ... with this engine's own tuning: names = ["team_late", ...] (fields of mm_tuning, include/mm_engine.h), values = <<v::little-32, ...>>
+  def create(_config, _tuning_names, _tuning_values), do: :erlang.nif_error(:nif_not_loaded)
   def close(_engine), do: :erlang.nif_error(:nif_not_loaded)
   def reset(_engine), do: :erlang.nif_error(:nif_not_loaded)
   def enqueue(_engine, _ratings, _cons, _groups), do: :erlang.nif_error(:nif_not_loaded)

@@ -67,7 +67,8 @@ defmodule Matchmaking.Search.EngineOwner do
   def init(opts) do
     config = Keyword.fetch!(opts, :config)            # binary mm_config
     modes = Keyword.fetch!(opts, :modes)              # [{"duel", teams, team_size}, ...] in mode-index order
-    case Engine.create(config) do
+    tuning = Keyword.get(opts, :tuning, [])           # [team_late: 0, ...]: this engine's mm_tuning (include/mm_engine.h); [] = defaults
+    case Engine.create(config, Enum.map(tuning, fn {k, _} -> Atom.to_string(k) end), for({_, v} <- tuning, into: <<>>, do: <<v::little-32>>)) do
       {:ok, engine} ->
         slots = :ets.new(:mm_slots, [:set, :private])     # {slot, payload, decoded id}
         ids = :ets.new(:mm_ids, [:bag, :private])         # {decoded id, slot}; a bag: the same id may be delivered twice

@@ -54,6 +54,8 @@ static int get_engine(ErlNifEnv* env, ERL_NIF_TERM t, nif_engine** r) {
     return enif_get_resource(env, t, ENGINE_T, (void**)r) && (*r)->e != NULL;
 }
 
+static int get_cstr_fwd(ErlNifEnv* env, ERL_NIF_TERM t, char* store, size_t cap, const char** out);   /* get_cstr, below */
+
 static int get_config(ErlNifEnv* env, ERL_NIF_TERM t, const mm_config** cfg) {
     ErlNifBinary b;
     if (!enif_inspect_binary(env, t, &b) || b.size != sizeof(mm_config)) return 0;
@@ -96,6 +98,38 @@ static ERL_NIF_TERM nif_create(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
     r->cfg = *cfg;
     ERL_NIF_TERM t = enif_make_resource(env, r);
     enif_release_resource(r); /* the term owns it now; engine_dtor runs at GC */
+    return enif_make_tuple2(env, A_OK, t);
+}
+
+/* create(config, [field_name], values) -> {:ok, engine}     mm_engine_create_ex: the engine with ITS tuning —
+ * field_name = a field of include/mm_engine.h's mm_tuning as a binary ("team_late"), values = <<v::little-32, ...>>, one per
+ * name; fields not named keep their defaults (built-in, or the MM_* environment variable's).  The per-worker configuration of
+ * search/worker.ex:54-66.  {:error, {-1, _}}: no such field; {:error, {-8, _}}: a value outside its field's range. */
+static ERL_NIF_TERM nif_create_tuned(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+    (void)argc;
+    const mm_config* cfg; mm_engine* e = NULL; ErlNifBinary vals; unsigned n = 0;
+    if (!get_config(env, argv[0], &cfg) || !enif_get_list_length(env, argv[1], &n) ||
+        !enif_inspect_binary(env, argv[2], &vals) || vals.size != (size_t)n * 4)
+        return enif_make_badarg(env);
+    mm_tuning tn;
+    tn.size = (uint32_t)sizeof tn;
+    int rc = mm_tuning_default(&tn);
+    ERL_NIF_TERM list = argv[1], head;
+    for (unsigned i = 0; i < n && !rc; i++) {
+        char name[64]; const char* nm; uint32_t v;
+        if (!enif_get_list_cell(env, list, &head, &list) || !get_cstr_fwd(env, head, name, sizeof name, &nm) || nm == NULL)
+            return enif_make_badarg(env);
+        memcpy(&v, vals.data + (size_t)i * 4, 4);
+        rc = mm_tuning_set(&tn, nm, v);
+    }
+    if (!rc) rc = mm_engine_create_ex(cfg, &tn, &e);
+    if (rc) return err(env, rc);
+    nif_engine* r = (nif_engine*)enif_alloc_resource(ENGINE_T, sizeof(*r));
+    if (!r) { mm_engine_destroy(e); return err(env, MM_ERR_OOM); }
+    r->e = e;
+    r->cfg = *cfg;
+    ERL_NIF_TERM t = enif_make_resource(env, r);
+    enif_release_resource(r);
     return enif_make_tuple2(env, A_OK, t);
 }
 
@@ -262,6 +296,10 @@ static int get_cstr(ErlNifEnv* env, ERL_NIF_TERM t, char* store, size_t cap, con
     return 1;
 }
 
+static int get_cstr_fwd(ErlNifEnv* env, ERL_NIF_TERM t, char* store, size_t cap, const char** out) {
+    return get_cstr(env, t, store, cap, out);
+}
+
 /* decode(config, [mode_name], region_key | nil, party_key | nil, role_key | nil, payloads, offsets)
  *   -> {:ok, ratings, cons, groups, status, id_offsets, id_lengths}
  * payloads = the deliveries of a tick period back to back, offsets = n+1 little-64 byte offsets.
@@ -343,6 +381,7 @@ static ErlNifFunc funcs[] = {
     {"default_config", 0, nif_default_config, 0},
     {"find_rating_group", 2, nif_find_rating_group, 0},
     {"create", 1, nif_create, ERL_NIF_DIRTY_JOB_IO_BOUND},       /* hipMalloc of the whole pool */
+    {"create", 3, nif_create_tuned, ERL_NIF_DIRTY_JOB_IO_BOUND}, /* ... with the engine's own mm_tuning */
     {"close", 1, nif_close, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"reset", 1, nif_reset, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"enqueue", 4, nif_enqueue, ERL_NIF_DIRTY_JOB_IO_BOUND},     /* H2D + bucketing kernels */

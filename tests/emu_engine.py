@@ -19,10 +19,10 @@ def load():
 class EmuEngine(EngineBase):
     _prefix = "mm_"
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, tuning=None):
         if EmuEngine._lib is None:
             EmuEngine._lib = load()
-        super().__init__(cfg)
+        super().__init__(cfg, tuning)
 
 
 def load_small():
@@ -38,7 +38,7 @@ class EmuEngineSmall(EngineBase):
     _prefix = "mm_"
     _lib = None
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, tuning=None):
         if EmuEngineSmall._lib is None:
             EmuEngineSmall._lib = load_small()
-        super().__init__(cfg)
+        super().__init__(cfg, tuning)

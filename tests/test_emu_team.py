@@ -215,23 +215,21 @@ def test_kt_late_hands_a_chain_back_after_a_rich_pass(oracle_cls, monkeypatch):
                  weights=[0.2] * 5, capacity=1 << 15) > 300
 
 
-@pytest.mark.parametrize("f2,live,fused,split", [("0", "1", "0", "1"), ("0", "1", "1", "1"), ("2", "1", "1", "1"), ("1000", "0", "1", "1"),
-                                                 ("1000", "0", "1", "0"), ("0", "0", "0", "1")])
-def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused, split):
-    """A pass is kt_f + kt_chase + kt_emit as three launches, or kt_f and the chase in one (kt_fc: MM_TEAM_LIVE, the
-    passes from MM_TEAM_F2 on), or with the emitter workgroups riding in the chase's launch (MM_TEAM_FUSED) — every
-    combination must give the oracle's ticks: cancel ticks, stored lobbies, the scan cap, the starving stream.  (Under
-    the shim the workgroups of a launch run one after another, the ones that wait last: this tests the roles' logic and
-    the publish / take protocol, not their overlap — test_gpu_parity.py does that.)"""
+@pytest.mark.parametrize("f2,split", [("0", "1"), ("2", "1"), ("1000", "1"), ("1000", "0")])
+def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, split):
+    """A pass is kt_f | kt_f2 | kt_chase (the first MM_TEAM_F2 passes of a tick; the stored lobby's fill in kt_f's launch or
+    in kt_chase's: MM_TEAM_SPLIT) or kt_f, the chase and the emitters in ONE launch (kt_fc, the passes from MM_TEAM_F2 on) —
+    every combination must give the oracle's ticks: cancel ticks, stored lobbies, the scan cap, the starving stream.  (Rounds
+    2-5 also had kt_f | kt_chase | kt_emit one behind the other, MM_TEAM_LIVE=0 / MM_TEAM_FUSED=0: taken out in round 6.
+    Under the shim the workgroups of a launch run one after another, the ones that wait last: this tests the roles' logic
+    and the publish / take protocol, not their overlap — test_gpu_parity.py does that.)"""
     from helpers import run_starving_team_stream
     monkeypatch.setenv("MM_TEAM_F2", f2)
-    monkeypatch.setenv("MM_TEAM_LIVE", live)
-    monkeypatch.setenv("MM_TEAM_FUSED", fused)
     monkeypatch.setenv("MM_TEAM_SPLIT", split)         # the stored lobby's fill from the head of the queue in kt_f's launch (the passes with kt_f2) or in kt_chase's
     monkeypatch.setenv("MM_TEAM_LATE", "0")
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=13, weights=W5) > 50
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=14, regions=2) > 50
-    if (f2, live, fused) == ("0", "1", "1"):             # the shipped shape: the scan cap and the starving stream too
+    if f2 == "0":                                        # kt_fc from the first pass: the scan cap and the starving stream too
         assert ticks(oracle_cls, EmuEngineSmall, mode_team(4, 2, 30, (2, 1, 1)), 3000, seed=15, lo=0, hi=900) > 20   # narrow window: the scan cap
         per, depth = run_starving_team_stream(EmuEngineSmall, oracle_cls, preload=6000, ticks=6, per_tick=80, cancels=9,
                                               capacity=1 << 14)
@@ -242,8 +240,8 @@ def test_every_launch_shape_of_a_pass(oracle_cls, monkeypatch, f2, live, fused, 
         random_scenario(rng, cfg, a, b, n_rounds=4, batch=1500, cancel_frac=0.05)
 
 
-@pytest.mark.parametrize("nowait,fused", [("1", "1"), ("2", "1"), ("3", "0")])
-def test_a_chaser_that_gets_no_flag_looks_the_lobby_up_itself(oracle_cls, monkeypatch, nowait, fused):
+@pytest.mark.parametrize("nowait", ["1", "2", "3"])
+def test_a_chaser_that_gets_no_flag_looks_the_lobby_up_itself(oracle_cls, monkeypatch, nowait):
     """kt_fc: the chaser waits a bounded number of polls (MM_TEAM_FWAIT) for the flag of a kt_f chunk — a workgroup that
     may not have found a CU yet when somebody else's kernels hold them — and then looks the lobby up itself, which is what it
     does for anchors beyond kt_f's horizon anyway; the emitter is told (TV_LOOKED in vis[]) not to trust kt_f's record of
@@ -252,8 +250,6 @@ def test_a_chaser_that_gets_no_flag_looks_the_lobby_up_itself(oracle_cls, monkey
     from helpers import run_starving_team_stream
     monkeypatch.setenv("MM_TEAM_NOWAIT", nowait)
     monkeypatch.setenv("MM_TEAM_F2", "0")               # kt_fc from the first pass
-    monkeypatch.setenv("MM_TEAM_LIVE", "1")
-    monkeypatch.setenv("MM_TEAM_FUSED", fused)
     monkeypatch.setenv("MM_TEAM_LATE", "0")
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(5, 2, 50, (1, 1, 1, 1, 1)), 2500, seed=17, weights=W5) > 50
     assert ticks(oracle_cls, EmuEngineSmall, mode_team(2, 3, 500, (2,)), 1500, seed=18, regions=2) > 50
@@ -295,7 +291,6 @@ def test_path_stats_count_the_chunk_flags_that_did_not_come(oracle_cls, monkeypa
     chunk's flag from coming (MM_TEAM_NOWAIT=3) — the anchors the chaser looked up itself, with `degraded` set: a late
     chunk is a slower pass, and the tick's record says so ("What's weak" 8: 'same for kt_fc chunk time-outs')."""
     monkeypatch.setenv("MM_TEAM_F2", "0")               # kt_fc from the first pass
-    monkeypatch.setenv("MM_TEAM_LIVE", "1")
     monkeypatch.setenv("MM_TEAM_LATE", "0")
     cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 13)
     from microservice_matchmaking_amd.synth import ROLE_WEIGHTS_5V5, make_pool

@@ -70,13 +70,6 @@ def test_tiled_extreme_ratings_fall_back(oracle_cls):
         assert_same_state(a, b, cfg)
 
 
-def test_tiled_three_launch_variant(oracle_cls, monkeypatch):
-    """MM_PAIR_FUSED=0 keeps the round as three launches (kp_tile_prep, kp_route, kp_tile_apply);
-    same results as the fused launch and as the oracle."""
-    monkeypatch.setenv("MM_PAIR_FUSED", "0")
-    assert two_ticks(oracle_cls, 6000, seed=9, window=40, regions=4) > 100
-
-
 def test_forced_generic_walk(oracle_cls, monkeypatch):
     """MM_FORCE_GENERIC=1 walks 1v1 modes with k_walk as well (the A/B switch of the bench)."""
     monkeypatch.setenv("MM_FORCE_GENERIC", "1")

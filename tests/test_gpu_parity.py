@@ -370,8 +370,25 @@ def test_gpu_randomised_stress_short(gpu_cls, monkeypatch):
     spec = importlib.util.spec_from_file_location("gpu_stress", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    monkeypatch.setattr("sys.argv", ["gpu_stress.py", "10", "3"])
-    mod.main()
+    mod.main(["10", "3"])
+
+
+@pytest.mark.parametrize("what", ["pair", "team"])
+def test_gpu_randomised_stress_with_fuzzed_knobs(gpu_cls, what, capsys):
+    """Twenty seconds each of tests/stress.py --fuzz-knobs (round 6): every scenario's engine is created with a random
+    COMBINATION of mm_tuning fields off their defaults — batch sizes, kp_rounds on / off / stopped at a random iteration by
+    the test hook, bounded waits of zero, kt_fc chunk flags that never come — and every tick is bit-exact against the oracle.
+    Round 5's tile-length bug (DESIGN.md section 4.3) was invisible to every default-configuration test for three rounds;
+    this is the tier the driver runs.  The soak (tens of thousands of scenarios): profiles/r06_stress_fuzz_knobs.txt."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress.py")
+    spec = importlib.util.spec_from_file_location("gpu_stress_fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["20", "6" if what == "pair" else "7"] + (["team"] if what == "team" else []) + ["--fuzz-knobs"])
+    out = capsys.readouterr().out
+    assert "--fuzz-knobs" in out and "scenarios ok" in out, out
 
 
 def test_gpu_pair_second_route_level_forced(gpu_cls, oracle_cls, monkeypatch):
@@ -398,16 +415,14 @@ def test_gpu_pair_second_route_level_forced(gpu_cls, oracle_cls, monkeypatch):
             live = np.setdiff1d(live, ma.slots.ravel())
 
 
-@pytest.mark.parametrize("f2,live,fused,split", [("0", "1", "0", "1"), ("0", "1", "1", "1"), ("1000", "0", "1", "1"), ("1000", "0", "1", "0"),
-                                                 ("32", "0", "0", "1")])
-def test_gpu_team_every_launch_shape_of_a_pass(gpu_cls, oracle_cls, monkeypatch, f2, live, fused, split):
-    """The three ways a pass of the team path is launched — kt_f / kt_chase / kt_emit one behind the other; kt_f and
-    the chase in one launch (kt_fc, the chasers taking F chunk by chunk while kt_f is still at work: MM_TEAM_LIVE, from
-    pass MM_TEAM_F2 on); the emitter workgroups in the chase's launch (MM_TEAM_FUSED) — on the device, where the
-    workgroups of a launch really overlap: 200k-player 5v5 pool, then arrivals + cancels, and a dense 3 x 2 mode."""
+@pytest.mark.parametrize("f2,split", [("0", "1"), ("1000", "1"), ("1000", "0"), ("3", "1")])
+def test_gpu_team_every_launch_shape_of_a_pass(gpu_cls, oracle_cls, monkeypatch, f2, split):
+    """The ways a pass of the team path is launched — kt_f | kt_f2 | kt_chase (the first MM_TEAM_F2 passes; the stored
+    lobby's fill in kt_f's launch or in kt_chase's: MM_TEAM_SPLIT) and kt_f, the chase and the emitters in one launch
+    (kt_fc, the chasers taking F chunk by chunk while kt_f is still at work) — on the device, where the workgroups of a
+    launch really overlap: 200k-player 5v5 pool, then arrivals + cancels, and a dense 3 x 2 mode.  (kt_f | kt_chase |
+    kt_emit one behind the other, rounds 2-5's MM_TEAM_LIVE=0 / MM_TEAM_FUSED=0, was taken out in round 6.)"""
     monkeypatch.setenv("MM_TEAM_F2", f2)
-    monkeypatch.setenv("MM_TEAM_LIVE", live)
-    monkeypatch.setenv("MM_TEAM_FUSED", fused)
     monkeypatch.setenv("MM_TEAM_SPLIT", split)         # the stored lobby's fill in kt_f's launch, beside its chunks (the passes with kt_f2), or in kt_chase's
     cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 19)
     rng = np.random.default_rng(17)
@@ -435,7 +450,7 @@ def test_gpu_team_every_launch_shape_of_a_pass(gpu_cls, oracle_cls, monkeypatch,
             assert_same_state(a, b, cfg, "launch shape 3x2 tick %d" % tick)
 
 
-@pytest.mark.parametrize("env", [{"MM_TEAM_NOWAIT": "3"}, {"MM_TEAM_FWAIT": "0"}, {"MM_TEAM_FWAIT": "0", "MM_TEAM_FUSED": "0"}])
+@pytest.mark.parametrize("env", [{"MM_TEAM_NOWAIT": "3"}, {"MM_TEAM_FWAIT": "0"}, {"MM_TEAM_FWAIT": "0", "MM_TEAM_EMIT_MAX": "1"}])
 def test_gpu_team_chaser_without_the_flag_of_a_chunk(gpu_cls, oracle_cls, monkeypatch, env):
     """kt_fc's chaser waits a bounded number of polls for the flag of a kt_f chunk (MM_TEAM_FWAIT; a workgroup that has
     found no CU yet because somebody else's kernels hold them) and then looks the lobby up itself and tells the emitter not
@@ -443,7 +458,6 @@ def test_gpu_team_chaser_without_the_flag_of_a_chunk(gpu_cls, oracle_cls, monkey
     where the chunk's workgroup really writes its records while the emitter collects the lobby again: MM_TEAM_FWAIT=0 gives
     up on every flag that is not up at the first look, MM_TEAM_NOWAIT=3 never sees the flag of every third chunk."""
     monkeypatch.setenv("MM_TEAM_F2", "0")
-    monkeypatch.setenv("MM_TEAM_LIVE", "1")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cfg = make_config([mode_team(5, 2, 50, (1, 1, 1, 1, 1))], capacity=1 << 18)
@@ -622,7 +636,13 @@ def test_gpu_two_engines_tick_concurrently(gpu_cls, oracle_cls, mode):
         with oracle_cls(cfg) as o:
             o.enqueue(rating, cons)
             want.append(o.tick(0))
-    engines = [gpu_cls(cfg) for _ in range(2)]
+    # (round 6) the two engines of one process run with DIFFERENT tuning — per-engine records (mm_engine_create_ex), where
+    # rounds 1-5 read process-wide MM_* variables: the second one takes the short batches and the fall-back shapes
+    tunings = [None, {"pair_ptiles": 8, "pair_pbatch": 6, "pair_batch": 5} if mode == "1v1" else
+               {"team_f2": 3, "team_batch": 2, "team_late": 0, "team_rebuild": 3, "team_emit_max": 2}]
+    engines = [gpu_cls(cfg, tunings[k]) for k in range(2)]
+    assert engines[0].tuning() == gpu_cls.tuning_defaults()
+    assert all(engines[1].tuning()[f] == v for f, v in tunings[1].items()) and engines[1].tuning() != engines[0].tuning()
     got = [[None] * 3 for _ in range(2)]
     errors = []
     start = threading.Barrier(2)

@@ -33,13 +33,13 @@ def u32(b):
 
 def test_function_table_is_what_the_elixir_module_declares(beam):
     assert beam.module == "Elixir.Matchmaking.Search.Engine"
-    assert set(beam.table) == {("default_config", 0), ("find_rating_group", 2), ("create", 1), ("close", 1),
+    assert set(beam.table) == {("default_config", 0), ("find_rating_group", 2), ("create", 1), ("create", 3), ("close", 1),
                                ("reset", 1), ("enqueue", 4), ("cancel", 2), ("tick", 2), ("queue_depth", 2), ("path_stats", 1),
                                ("queue_slots", 3), ("lobby_state", 3), ("snapshot", 1), ("restore", 2), ("decode", 7),
                                ("encode_lobby", 4)}
     # whatever can block on the device is a dirty NIF; tick blocks on the stream -> CPU bound
     assert beam.table[("tick", 2)][1] == DIRTY_CPU
-    for k in (("create", 1), ("enqueue", 4), ("cancel", 2), ("snapshot", 1), ("restore", 2), ("queue_depth", 2)):
+    for k in (("create", 1), ("create", 3), ("enqueue", 4), ("cancel", 2), ("snapshot", 1), ("restore", 2), ("queue_depth", 2)):
         assert beam.table[k][1] == DIRTY_IO, k
     # the Elixir stubs (native/elixir/search_engine.ex) declare exactly these name/arity pairs
     import os
@@ -65,10 +65,14 @@ def test_default_config_and_rating_groups(beam):
         beam.call("find_rating_group", b, "high")
 
 
-def scenario(beam, n=6000, seed=5):
+def scenario(beam, n=6000, seed=5, tuning=None):
     """enqueue -> tick -> cancel -> tick for both modes, every reply checked against the oracle."""
     cfg = make_config(MODES, capacity=1 << max(14, int(n).bit_length() + 1))
-    ok, eng = beam.call("create", cfg_bin(cfg))
+    if tuning is None:
+        ok, eng = beam.call("create", cfg_bin(cfg))
+    else:                                                     # create/3: this engine's own mm_tuning, fields by name
+        ok, eng = beam.call("create", cfg_bin(cfg), [k.encode() for k in tuning],
+                            np.asarray(list(tuning.values()), "<u4").tobytes())
     assert ok == "ok" and isinstance(eng, Resource)
     rating, cons = make_pool(n, seed=seed, role_weights=ROLE_WEIGHTS_5V5)
     team = np.arange(n) % 3 == 0                              # a third plays mode 1; duel players have no role
@@ -112,6 +116,22 @@ def scenario(beam, n=6000, seed=5):
 
 def test_search_through_the_nif_matches_the_oracle(beam):
     scenario(beam)
+    beam.gc()
+    assert beam.live_resources() == 0
+
+
+def test_create_3_gives_the_engine_its_own_tuning(beam):
+    """create(config, names, values) = mm_engine_create_ex: the per-worker configuration (search/worker.ex:54-66) instead of
+    process-wide MM_* variables.  Results are the oracle's whatever the tuning; a field that does not exist and a value
+    outside its range are errors of create, never a silently ignored knob."""
+    scenario(beam, n=5000, seed=6, tuning={"team_late": 0, "team_f2": 1, "pair_ptiles": 3, "pair_batch": 2, "team_batch": 1})
+    cfg = make_config(MODES, capacity=1 << 12)
+    err = beam.call("create", cfg_bin(cfg), [b"no_such_knob"], np.asarray([1], "<u4").tobytes())
+    assert err[0] == "error" and err[1][0] == -1
+    err = beam.call("create", cfg_bin(cfg), [b"pair_ptiles"], np.asarray([33], "<u4").tobytes())
+    assert err[0] == "error" and err[1][0] == -8
+    with pytest.raises(BadArg):
+        beam.call("create", cfg_bin(cfg), [b"team_late"], b"")          # one value per name
     beam.gc()
     assert beam.live_resources() == 0
 
