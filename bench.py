@@ -86,7 +86,13 @@ def load_traffic(path, players, mode, detail=None):
         rows = sorted(((2.0 * v.get("fetch_raw", 0.0) + v.get("write_raw", 0.0)) * 1024.0, k, v) for k, v in per.items())
         detail["traffic_by_kernel"] = [{"kernel": k, "bytes_per_tick": b, "dispatches_per_tick": v.get("dispatches_per_tick")}
                                        for b, k, v in reversed(rows[-3:])]
-        detail["predicate_tests_physical"] = tj.get("predicate_tests_physical")
+        # round 6: every walk kernel's bytes AND time per tick (the rocprofv3 summaries the file was made from), heaviest first
+        tm = tj.get("per_kernel_time") or {}
+        detail["by_kernel_profiled"] = [
+            {"kernel": k, "hbm_bytes_per_tick": b, "launches_per_tick": v.get("dispatches_per_tick"),
+             "us_per_tick": (tm.get(k) or {}).get("us_per_tick"), "avg_us_per_launch": (tm.get(k) or {}).get("avg_us"),
+             "gbs": (b / ((tm.get(k) or {}).get("us_per_tick") * 1e-6) / 1e9) if (tm.get(k) or {}).get("us_per_tick") else None}
+            for b, k, v in reversed(rows)]
     return tj.get("walk_hbm_bytes_per_tick"), None
 
 
@@ -104,21 +110,70 @@ CRIT = {"barrier_us": 4277 / 2400.0,          # profiles/r04_pair_phase_timers.t
         "boundary_us_default": 2.4}           # kp_round to kp_round (profiles/r02_kernel_passes_1m_1v1.txt) when not measured here
 
 
-def critical_path_ms(path, boundary_us=None):
+def measured_primitives(path):
+    """The pair chain's serial primitives as THIS run's tick timed them (mm_path_stats, round 6): the shader clock from kp_late's
+    chase (cycles over 100 MHz ticks), the flag barrier and the L2-hit hop from tile 1's walker of the critical chain.  Falls
+    back, field by field, to the round-4 constants of CRIT (a library without the counters, a tick without kp_rounds)."""
+    prim = dict(CRIT)
+    src = {k: "constant (profiles/r04_*)" for k in ("barrier_us", "hop_l2_us")}
+    mhz = 2400.0
+    if path and path.get("clk_cycles") and path.get("clk_wall_ticks"):
+        mhz = 100.0 * path["clk_cycles"] / path["clk_wall_ticks"]
+        src["clock_mhz"] = "kp_late's chase: clk_cycles / clk_wall_ticks x 100 MHz"
+    else:
+        src["clock_mhz"] = "constant 2400"
+    if path and path.get("crit_timed_passes") and path.get("crit_barrier_cycles"):
+        prim["barrier_us"] = path["crit_barrier_cycles"] / path["crit_timed_passes"] / mhz
+        src["barrier_us"] = "measured in this run: crit_barrier_cycles / crit_timed_passes / clock"
+    if path and path.get("crit_timed_hops") and path.get("crit_hop_cycles"):
+        prim["hop_l2_us"] = path["crit_hop_cycles"] / path["crit_timed_hops"] / mhz
+        src["hop_l2_us"] = "measured in this run: crit_hop_cycles / crit_timed_hops / clock"
+    prim["clock_mhz"] = mhz
+    return prim, src
+
+
+def critical_path_ms(path, boundary_us=None, prim=None):
     """(ms, parts) of the pair path's serial critical path for the tick `path` (mm_path_stats_get) describes, or (None, None)."""
-    if not path or not (path.get("paths", 0) & 2) or not path.get("crit_passes"):
+    if not path or not (path.get("paths", 0) & 2) or not path.get("crit_passes") or path.get("crit_group") == 0xFFFFFFFF:
         return None, None
+    prim = prim or CRIT
     b = boundary_us if boundary_us else CRIT["boundary_us_default"]
     rp, rh = path["crit_rounds_passes"], path["crit_rounds_hops"]
     hops_per_pass = (rh / rp) if rp else 0.0
-    parts = {"kp_rounds": (rp * CRIT["barrier_us"] + rh * CRIT["hop_l2_us"]) * 1e-3,
-             "kp_round": path["crit_round_passes"] * (b + hops_per_pass * CRIT["hop_mem_us"]) * 1e-3,
-             "kp_late": (path["crit_late_lobbies"] * CRIT["late_step_us"] + path["crit_late_passes"] * CRIT["late_pass_us"]) * 1e-3}
+    parts = {"kp_rounds": (rp * prim["barrier_us"] + rh * prim["hop_l2_us"]) * 1e-3,
+             "kp_round": path["crit_round_passes"] * (b + hops_per_pass * prim["hop_mem_us"]) * 1e-3,
+             "kp_late": (path["crit_late_lobbies"] * prim["late_step_us"] + path["crit_late_passes"] * prim["late_pass_us"]) * 1e-3}
+    return sum(parts.values()), parts
+
+
+# The team path's serial chain (round 6; VERDICT r05 item 4b): what the critical chain's CHASER must do one thing after the other.
+#   a pass as kt_f | kt_f2 | kt_chase  = three kernel boundaries + one dependent (F, F o F) load per TWO lobbies, pulled through the
+#                                         chaser's L2 (169 cycles: profiles/r04_ubench_xwg_hop.txt "pulled")
+#   a pass as ONE kt_fc launch         = one boundary + one dependent F load per lobby from memory (470 cycles, same file)
+#   a pass inside kt_late              = no boundary; one trip to memory per lobby (the anchor's record)
+#   a look-up the chaser does itself   = four dependent trips to memory (where the roles' stretches begin, the stretches, the
+#                                         members' records, the bitmap behind the last member) at 982 cycles a trip on an idle
+#                                         device (profiles/r03_ubench_trip_latency.txt), three inside kt_late (the bitmap is in LDS)
+# kt_f's chunks, the emitters and the seats are parallel work beside it.
+TEAM_CRIT = {"hop_pulled_us": 169 / 2400.0, "hop_mem_us": 470 / 2400.0, "trip_us": 982 / 2400.0,
+             "lookup_trips": 4, "late_lookup_trips": 3}
+
+
+def team_critical_path_ms(path, boundary_us=None):
+    """(ms, parts) of the team path's serial critical path from mm_path_stats' crit_team_* counts, or (None, None)."""
+    if not path or not (path.get("paths", 0) & 4) or not path.get("crit_team_passes") or path.get("crit_team_group") in (None, 0xFFFFFFFF):
+        return None, None
+    b = boundary_us if boundary_us else CRIT["boundary_us_default"]
+    T = TEAM_CRIT
+    parts = {"kt_f|kt_f2|kt_chase": (path["crit_team_f_passes"] * 3 * b + 0.5 * path["crit_team_f_lobbies"] * T["hop_pulled_us"]) * 1e-3,
+             "kt_fc": (path["crit_team_fc_passes"] * b + path["crit_team_fc_lobbies"] * T["hop_mem_us"]) * 1e-3,
+             "kt_late": path["crit_team_late_lobbies"] * T["trip_us"] * 1e-3,
+             "look-ups": (path["crit_team_lookups"] * T["lookup_trips"] + path["crit_team_late_lookups"] * T["late_lookup_trips"]) * T["trip_us"] * 1e-3}
     return sum(parts.values()), parts
 
 
 def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passes_max, traffic,
-                   boundary_us=None, traffic_note=None, traffic_detail=None, path=None):
+                   boundary_us=None, traffic_note=None, traffic_detail=None, path=None, probe=None):
     """The `roofline` object of the bench line (pure arithmetic; tests/test_bench_line.py).
     SURVEY.md §8(d): achieved = algorithmic bytes / walk time, with its mandatory companions —
     (i) physical HBM GB/s (PMC traffic / walk time), (ii) the compulsory bytes of a tick
@@ -129,7 +184,7 @@ def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passe
                  "per pass, while a chain does not fit one XCD and as its fallback) + kp_late + kp_finish"
                  if mode == "1v1" else
                  "team walk: kt_build + per pass ONE launch kt_fc (kt_f, the chase and the emitters side by side; the first 32 "
-                 "lobby-rich passes kt_f + kt_f2 + kt_chase<1> with its emitters) + kt_late (the last passes in one launch)")
+                 "lobby-rich passes kt_f + kt_f2 + kt_chase with its emitters) + kt_late (the last passes in one launch)")
     achieved = pairs * bytes_per_pair / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
     compulsory = float(players) * (12 + 8)
     floor_ms = passes_max * boundary_us * 1e-3 if boundary_us else None
@@ -158,14 +213,28 @@ def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passe
                     "per-pass F pointers (who the cursor picks after each player's lobby) "
                     "computed for every queued player at once"),
     }
-    cp, cparts = critical_path_ms(path, boundary_us)
+    prim, prim_src = measured_primitives(path)
+    cp, cparts = critical_path_ms(path, boundary_us, prim)
+    tcp, tparts = team_critical_path_ms(path, boundary_us)
+    if tcp is not None:
+        out["critical_path_ms"] = tcp
+        out["frac_of_critical_path"] = (tcp / walk_ms) if walk_ms > 0 else None
+        out["critical_path_model"] = {
+            "parts_ms": tparts, "primitives_us": dict(TEAM_CRIT, boundary_us=boundary_us or CRIT["boundary_us_default"]),
+            "passes": {"kt_f|kt_f2|kt_chase": path["crit_team_f_passes"], "kt_fc": path["crit_team_fc_passes"], "kt_late": path["crit_team_late_passes"]},
+            "lobbies": {"by F o F hops": path["crit_team_f_lobbies"], "by F hops": path["crit_team_fc_lobbies"], "inside kt_late": path["crit_team_late_lobbies"]},
+            "lookups": {"pass kernels": path["crit_team_lookups"], "kt_late": path["crit_team_late_lookups"]},
+            "what": "the chain with the most passes (rating group %d), its chaser alone: kernel boundaries, one dependent load per lobby "
+                    "(per two with F o F), four dependent trips to memory per look-up it does itself (the stored lobby's fill, the lobby a "
+                    "pass ends on); kt_f's chunks, the emitters and the seats are parallel work beside it" % path["crit_team_group"]}
     if cp is not None:
         # latency_floor_ms above is the floor of a one-launch-per-pass design and is kept for continuity with rounds 1-4;
         # the path that runs now has no kernel boundary in most passes: this is the ceiling that applies to it
         out["critical_path_ms"] = cp
         out["frac_of_critical_path"] = (cp / walk_ms) if walk_ms > 0 else None
         out["critical_path_model"] = {
-            "parts_ms": cparts, "primitives_us": {k: v for k, v in CRIT.items() if k != "boundary_us_default"},
+            "parts_ms": cparts, "primitives_us": {k: v for k, v in prim.items() if k != "boundary_us_default"},
+            "primitives_source": prim_src,
             "passes": {"kp_rounds": path["crit_rounds_passes"], "kp_round": path["crit_round_passes"], "kp_late": path["crit_late_passes"]},
             "hops_in_kp_rounds": path["crit_rounds_hops"], "lobbies_in_kp_late": path["crit_late_lobbies"],
             "what": "the chain with the most passes (rating group %d): barrier + route hops per pass inside kp_rounds, kernel boundary "
@@ -175,7 +244,33 @@ def roofline_block(mode, pairs, bytes_per_pair, walk_ms, step_ms, players, passe
     if traffic is not None:
         out["traffic_over_algorithmic"] = traffic / (pairs * bytes_per_pair) if pairs else None
     out["traffic_by_kernel"] = (traffic_detail or {}).get("traffic_by_kernel")
-    out["predicate_tests_physical"] = (traffic_detail or {}).get("predicate_tests_physical")
+    # round 6: the walk's kernels one by one.  Time and HBM bytes per tick are the profile's (the same
+    # rocprofv3 summaries `traffic` comes from, bound to the kernel sources by hash); kp_nx_init — north_star's kernel: coalesced
+    # SoA keys, an LDS-staged candidate window, a wave-ballot arg-min per anchor — is also timed LIVE in this run (HIP events on the
+    # engine's stream) and priced by SURVEY.md 8(d)'s convention: candidates it physically tested x 8 B / its duration.  That figure
+    # is LDS traffic, not HBM traffic: it is labelled as such and is never `frac`.
+    by = list((traffic_detail or {}).get("by_kernel_profiled") or [])
+    tests = (probe or {}).get("tests_all")
+    out["predicate_tests_physical"] = tests
+    if mode == "1v1" and path and path.get("pair_nx_init_ns"):
+        us = path["pair_nx_init_ns"] / 1e3
+        nx = {"kernel": "kp_nx_init", "duration_us_live": us, "tested_candidates": (probe or {}).get("tests_nx_init"),
+              "label": "LDS-staged, SURVEY 8(d) convention (8 B per tested candidate); LDS bytes, not HBM bytes: never `frac`"}
+        if nx["tested_candidates"]:
+            gbs = nx["tested_candidates"] * 8.0 / (us * 1e-6) / 1e9
+            nx.update({"equiv_gbs": gbs, "equiv_frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                       "tests_per_s": nx["tested_candidates"] / (us * 1e-6)})
+        for row in by:
+            if row["kernel"].startswith("kp_nx_init"):
+                row.update(nx)
+                break
+        else:
+            by.append(nx)
+    out["by_kernel"] = by or None
+    if tests is not None:
+        out["predicate_tests_note"] = ("all pair kernels of one tick (next[] build, repairs, head scans, the LDS-resident walk), counted by a "
+                                       "second engine created with mm_tuning.pair_tune bit 13 (atomics: not the timed engine); "
+                                       "%.2f x the reference algorithm's pair evaluations" % (tests / pairs if pairs else 0.0))
     return out
 
 
@@ -213,6 +308,10 @@ def parse():
     ap.add_argument("--stream-qps", type=int, default=100_000)
     ap.add_argument("--stream-seconds", type=float, default=3.0)
     ap.add_argument("--stream-tick-ms", type=float, default=10.0)
+    ap.add_argument("--same-device", action="store_true",
+                    help="N > 1 ranks that all use GPU 0 and meet over gloo instead of RCCL (two RCCL ranks cannot share a device): "
+                         "what a 1-GPU box can run of the N > 1 branch — real HIP engines in N processes, the sharding, the "
+                         "gathers, the one JSON line; the line says same_device and its value is NOT a scaling number")
     ap.add_argument("--traffic-json", default=None,
                     help="optional PMC summary written by tools/make_traffic.py (default: profiles/traffic_latest*.json)")
     return ap.parse_args()
@@ -581,6 +680,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    if args.same_device:
+        local_rank = 0
     if world > 1 and torch.cuda.device_count() <= local_rank:
         print("bench.py: rank %d wants GPU %d, this node shows %d" % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
         sys.exit(3)
@@ -590,10 +691,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        ones = torch.ones(1).cuda()
-        dist.all_reduce(ones)                       # the ranks RCCL really connected: an all-reduce of ones
+        if args.same_device:
+            dist.init_process_group("gloo")
+            ones = torch.ones(1)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            ones = torch.ones(1).cuda()
+        dist.all_reduce(ones)                       # the ranks the collective really connected: an all-reduce of ones
         rccl_ranks = int(ones.item())
+    coll_dev = "cpu" if args.same_device else "cuda"
 
     from microservice_matchmaking_amd import Engine, make_config, mode_1v1, mode_team
     from microservice_matchmaking_amd.sharding import (ChainSharding, ShardedSearch, chain_weights, rating_groups,
@@ -757,6 +863,8 @@ def main():
             "unit": "matched players/s",
             "n_gpus": world,
             "rccl_ranks": rccl_ranks,
+            "collective_backend": "none" if world == 1 else ("gloo" if args.same_device else "nccl (RCCL)"),
+            "same_device": bool(args.same_device and world > 1),
             "launched_by": "bench.py itself (--gpus N without a launcher)" if os.environ.get("MM_BENCH_LAUNCHED") else
                            ("torch.distributed.run / env" if world > 1 else "single process"),
             "steps": args.steps,
@@ -918,9 +1026,9 @@ def main():
                     wm += int(wstep().stats["players_matched"])
                 fence()
                 wel = time.perf_counter() - t0
-            tt = torch.tensor([wel, 0.0], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([wel, 0.0], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ss = torch.tensor([float(wm)], device="cuda", dtype=torch.float64)
+            ss = torch.tensor([float(wm)], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(ss, op=dist.ReduceOp.SUM)
             if rank == 0:
                 line["weak_scaling"] = {"value": float(ss.item()) / float(tt[0].item()), "unit": "matched players/s",
@@ -958,7 +1066,19 @@ def main():
     if rank == 0:
         boundary_us = None if args.no_boundary else measure_boundary_us(torch)
         a = main_roofline_args
-        line["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9], a[10])
+        probe = None
+        if world == 1 and args.mode == "1v1":
+            # the predicate tests the pair kernels PHYSICALLY perform in one tick of the headline pool: a second engine whose
+            # mm_tuning has pair_tune bit 13 (the counters are atomics — never on the timed engine), one untimed step
+            rating_p, cons_p = pool_of(wl, n)
+            qcfg = make_config(wl["modes"], capacity=pow2(n), device=local_rank, timing=False)
+            with Engine(qcfg, {"pair_tune": 0x2000}) as qeng:
+                qeng.enqueue_device(torch.from_numpy(rating_p).cuda(), torch.from_numpy(cons_p.view(np.int32)).cuda())
+                qeng.tick(0)
+                qs = qeng.path_stats()
+            probe = {"tests_all": qs["pair_tested_lo"] + (qs["pair_tested_hi"] << 32),
+                     "tests_nx_init": qs["pair_tested_nx_lo"] + (qs["pair_tested_nx_hi"] << 32)}
+        line["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9], a[10], probe)
         if "cfg3" in line and "_roofline_args" in line["cfg3"]:
             a = line["cfg3"].pop("_roofline_args")
             line["cfg3"]["roofline"] = roofline_block(*a[:8], boundary_us, a[8], a[9], a[10])

@@ -384,6 +384,28 @@ typedef struct mm_path_stats {
     uint32_t crit_late_lobbies;    /* lobbies it emitted inside kp_late (one dependent LDS step each) */
     uint32_t degraded;             /* 1: a fall-back was in force during that tick (a stop, the cool-down, kp_rounds off, late flags):
                                          its timing is not the headline path's                    */
+    /* ---- round 6 (appended: a caller built against the shorter record gets the shorter record) ----
+     * the primitives of the pair path's serial chain as tile 1's walker of the critical chain timed them in that tick */
+    uint32_t crit_timed_passes;    /* passes inside kp_rounds it timed                                                     */
+    uint32_t crit_timed_hops;      /* route hops it took in them                                                           */
+    uint32_t crit_barrier_cycles;  /* shader-clock cycles it spent at the chain's flag barrier, summed over those passes   */
+    uint32_t crit_hop_cycles;      /* ... in the scalar hop loop (L2-hit hops)                                             */
+    uint32_t clk_cycles;           /* a stretch of kp_late (the critical chain's chase) in shader-clock cycles ...         */
+    uint32_t clk_wall_ticks;       /* ... and in ticks of the constant 100 MHz counter: clk_cycles / clk_wall_ticks x 100 MHz = the clock */
+    uint32_t pair_nx_init_ns;      /* kp_nx_init (next[] for everybody: the LDS-staged masked arg-min), HIP events (MM_CFG_TIMING; else 0) */
+    uint32_t pair_tested_lo, pair_tested_hi;       /* mm_tuning.pair_tune bit 13: predicate tests the pair kernels physically performed in that tick ... */
+    uint32_t pair_tested_nx_lo, pair_tested_nx_hi; /* ... of them in kp_nx_init (0 without the bit: the counters cost atomics)                         */
+    /* the team path's chain with the most passes: what its chaser did, by launch shape */
+    uint32_t crit_team_group;      /* its rating group (0xFFFFFFFF: the team path walked nothing)                          */
+    uint32_t crit_team_passes;
+    uint32_t crit_team_f_passes;   /* passes as kt_f | kt_f2 | kt_chase                                                    */
+    uint32_t crit_team_fc_passes;  /* passes as ONE kt_fc launch                                                           */
+    uint32_t crit_team_late_passes;/* passes inside kt_late                                                                */
+    uint32_t crit_team_f_lobbies;  /* lobbies its chaser reached by F o F hops (two a trip) ...                            */
+    uint32_t crit_team_fc_lobbies; /* ... by single F hops beside kt_f's chunks ...                                        */
+    uint32_t crit_team_late_lobbies;/* ... by its own look at the anchor's record inside kt_late                           */
+    uint32_t crit_team_lookups;    /* look-ups the chaser did itself in the pass kernels (stored lobby's fill, the lobby a pass ends on, anchors without F) */
+    uint32_t crit_team_late_lookups;/* ... inside kt_late                                                                  */
 } mm_path_stats;
 int mm_path_stats_get(mm_engine* e, mm_path_stats* out);
 

@@ -83,7 +83,11 @@ class MMPathStats(C.Structure):
         "team_f_launches", "team_fc_launches", "team_late_launches", "team_build_launches",
         "team_flags_late", "team_flags_late_total",
         "crit_group", "crit_passes", "crit_rounds_passes", "crit_rounds_hops", "crit_round_passes", "crit_late_passes",
-        "crit_late_lobbies", "degraded")]
+        "crit_late_lobbies", "degraded",
+        "crit_timed_passes", "crit_timed_hops", "crit_barrier_cycles", "crit_hop_cycles", "clk_cycles", "clk_wall_ticks",
+        "pair_nx_init_ns", "pair_tested_lo", "pair_tested_hi", "pair_tested_nx_lo", "pair_tested_nx_hi",
+        "crit_team_group", "crit_team_passes", "crit_team_f_passes", "crit_team_fc_passes", "crit_team_late_passes",
+        "crit_team_f_lobbies", "crit_team_fc_lobbies", "crit_team_late_lobbies", "crit_team_lookups", "crit_team_late_lookups")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "size"}

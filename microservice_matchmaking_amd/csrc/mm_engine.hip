@@ -951,6 +951,8 @@ struct mm_engine {
     uint32_t n_chains;
     hipStream_t stream;
     hipEvent_t ev[4];
+    hipEvent_t ev_nx[2];                // around kp_nx_init (MM_CFG_TIMING): mm_path_stats.pair_nx_init_ns
+    bool ev_nx_set;
     hipEvent_t ev_grp[MM_MAX_GROUPS];   // a group's match list has reached the host
     int last_hip;
     // device
@@ -1342,6 +1344,8 @@ extern "C" void mm_engine_destroy(mm_engine* e)
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (int i = 0; i < 4; ++i)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (int i = 0; i < 2; ++i)
+        if (e->ev_nx[i]) (void)hipEventDestroy(e->ev_nx[i]);
     for (uint32_t i = 0; i < MM_MAX_GROUPS; ++i)
         if (e->ev_grp[i]) (void)hipEventDestroy(e->ev_grp[i]);
     if (e->ev_copy_pending) (void)hipEventSynchronize(e->ev_copy);     // (nothing of this engine is left on the shared stream)
@@ -1582,6 +1586,8 @@ extern "C" int mm_engine_create_ex(const mm_config* cfg, const mm_tuning* tuning
         }
         CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         for (int i = 0; i < 4; ++i) CREATE_CHK(hipEventCreate(&e->ev[i]));
+        for (int i = 0; i < 2; ++i) CREATE_CHK(hipEventCreate(&e->ev_nx[i]));
+        e->ev_nx_set = false;
         for (uint32_t i = 0; i < cfg->n_groups; ++i) CREATE_CHK(hipEventCreate(&e->ev_grp[i]));
         if (copy_stream_acquire(cfg->device, &e->copy_stream)) { e->copy_stream = nullptr; mm_engine_destroy(e); return MM_ERR_HIP; }
         CREATE_CHK(hipEventCreate(&e->ev_copy));
@@ -2188,7 +2194,10 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
         if (e->pair_nxstage) stage = e->pair_nxstage;
         if (stage < seg + 64u) stage = seg + 64u;
         if (stage > NXI_STAGE) stage = NXI_STAGE;
+        const bool timing = (cfg.flags & MM_CFG_TIMING) != 0;
+        if (timing) HIPCHK(e, hipEventRecord(e->ev_nx[0], e->stream));
         hipLaunchKernelGGL(kp_nx_init, dim3((bound + seg - 1u) / seg + 1u, G), dim3(NXI_THREADS), 0, e->stream, P, seg, stage);
+        if (timing) { HIPCHK(e, hipEventRecord(e->ev_nx[1], e->stream)); e->ev_nx_set = true; }
     }
     HIPCHK(e, hipGetLastError());
     uint32_t tail_no[MM_MAX_GROUPS];
@@ -2796,6 +2805,8 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
     if (timing) HIPCHK(e, hipEventRecord(e->ev[2], e->stream));
     HIPCHK(e, hipMemcpyAsync(e->h_chains, e->d_chains, e->n_chains * sizeof(ChainDev), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    // (mm_path_stats: the pair chains' records as kp_late and kp_finish left them — the last look was taken before them)
+    if (use_pair) HIPCHK(e, hipMemcpyAsync(e->h_pchains, e->d_pchains, G * sizeof(PairChain), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     const double t_copy0 = host_now_ms();
     if (use_pair && e->pair_debug) {
@@ -2953,6 +2964,42 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
         e->ps.crit_round_passes = e->ps_hand[0][gc] >= e->ps_hand[2][gc] ? e->ps_hand[0][gc] - e->ps_hand[2][gc] : 0u;
         e->ps.crit_late_passes = cd.passes >= e->ps_hand[0][gc] ? cd.passes - e->ps_hand[0][gc] : 0u;
         e->ps.crit_late_lobbies = cd.n_out >= e->ps_hand[1][gc] ? cd.n_out - e->ps_hand[1][gc] : 0u;
+        // the primitives of its serial chain as tile 1's walker timed them (PairChain.ptm), the clock (kp_late's chase in
+        // shader-clock cycles and in 100 MHz ticks), kp_nx_init by HIP events, the physical predicate tests (pair_tune bit 13)
+        const PairChain& pc = e->h_pchains[gc];
+        if (e->ps.crit_group != 0xFFFFFFFFu) {
+            e->ps.crit_timed_passes = pc.ptm[5];
+            e->ps.crit_timed_hops = pc.ptm[15];
+            e->ps.crit_barrier_cycles = pc.ptm[0];
+            e->ps.crit_hop_cycles = pc.ptm[3];
+            e->ps.clk_cycles = pc.dbg[5];
+            e->ps.clk_wall_ticks = pc.dbg[6];
+        }
+        if (e->ev_nx_set) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e->ev_nx[0], e->ev_nx[1]) == hipSuccess) e->ps.pair_nx_init_ns = (uint32_t)(ms * 1e6f);
+            e->ev_nx_set = false;
+        }
+        if (e->pair_tune & 0x2000u) {
+            unsigned long long t = 0, tn = 0;
+            for (uint32_t g = 0; g < G; ++g) if (e->h_pchains[g].fast) { t += e->h_pchains[g].tested; tn += e->h_pchains[g].tested_nx; }
+            e->ps.pair_tested_lo = (uint32_t)t; e->ps.pair_tested_hi = (uint32_t)(t >> 32);
+            e->ps.pair_tested_nx_lo = (uint32_t)tn; e->ps.pair_tested_nx_hi = (uint32_t)(tn >> 32);
+        }
+    }
+    e->ps.crit_team_group = 0xFFFFFFFFu;
+    if (e->ps.paths & MM_PATH_TEAM) {            // ... and the team path's: what its chaser did, by launch shape (TeamChain.cp)
+        uint32_t gc = 0xFFFFFFFFu;
+        for (uint32_t g = 0; g < G; ++g)
+            if (e->h_tchains[g].fast && (gc == 0xFFFFFFFFu || e->h_tchains[g].passes > e->h_tchains[gc].passes)) gc = g;
+        if (gc != 0xFFFFFFFFu) {
+            const TeamChain& t = e->h_tchains[gc];
+            e->ps.crit_team_group = gc;
+            e->ps.crit_team_passes = t.passes;
+            e->ps.crit_team_f_passes = t.cp[0]; e->ps.crit_team_fc_passes = t.cp[1]; e->ps.crit_team_late_passes = t.cp[2];
+            e->ps.crit_team_f_lobbies = t.cp[3]; e->ps.crit_team_fc_lobbies = t.cp[4]; e->ps.crit_team_late_lobbies = t.cp[5];
+            e->ps.crit_team_lookups = t.cp[6]; e->ps.crit_team_late_lookups = t.cp[7];
+        }
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));

@@ -59,6 +59,46 @@ def test_critical_path_model_is_barriers_hops_boundaries_and_lds_steps():
     assert bench.critical_path_ms(None) == (None, None) and bench.critical_path_ms({"paths": 4, "crit_passes": 9}) == (None, None)
 
 
+def test_round6_line_measured_primitives_team_model_and_by_kernel():
+    """(c) the pair model's primitives come from the tick's own timers when mm_path_stats has them
+    (clock from kp_late's chase, barrier and L2-hit hop from tile 1's walker), (b) the team path has a critical-path model
+    of its own (the chaser's boundaries, dependent F loads and look-ups), (a) roofline.by_kernel lists the walk's kernels with
+    time and bytes and prices kp_nx_init by SURVEY 8(d)'s convention — labelled, never `frac`."""
+    path = {"paths": 2, "crit_group": 0, "crit_passes": 632, "crit_rounds_passes": 336, "crit_rounds_hops": 336 * 24,
+            "crit_round_passes": 26, "crit_late_passes": 270, "crit_late_lobbies": 7300,
+            "crit_timed_passes": 300, "crit_timed_hops": 7200, "crit_barrier_cycles": 300 * 4400, "crit_hop_cycles": 7200 * 280,
+            "clk_cycles": 2_300_000, "clk_wall_ticks": 100_000, "pair_nx_init_ns": 150_000}
+    prim, src = bench.measured_primitives(path)
+    assert prim["clock_mhz"] == pytest.approx(2300.0) and prim["barrier_us"] == pytest.approx(4400 / 2300.0)
+    assert prim["hop_l2_us"] == pytest.approx(280 / 2300.0) and "measured in this run" in src["barrier_us"]
+    assert bench.measured_primitives({})[0]["barrier_us"] == bench.CRIT["barrier_us"]          # an older library: the constants
+    det = {"by_kernel_profiled": [{"kernel": "kp_rounds<8192u>", "hbm_bytes_per_tick": 1e8, "launches_per_tick": 8, "us_per_tick": 6000.0,
+                                    "avg_us_per_launch": 750.0, "gbs": 16.7},
+                                   {"kernel": "kp_nx_init", "hbm_bytes_per_tick": 2e7, "launches_per_tick": 1, "us_per_tick": 149.0,
+                                    "avg_us_per_launch": 149.0, "gbs": 134.0}]}
+    r = bench.roofline_block("1v1", 7e7, 8, 9.6, 10.3, 1_000_000, 632, 8.6e8, 2.0, None, det, path,
+                             {"tests_all": 300_000_000, "tests_nx_init": 140_000_000})
+    assert r["critical_path_model"]["primitives_us"]["barrier_us"] == pytest.approx(4400 / 2300.0)
+    assert r["predicate_tests_physical"] == 300_000_000 and "4.29 x" in r["predicate_tests_note"]
+    nx = [k for k in r["by_kernel"] if k["kernel"] == "kp_nx_init"][0]
+    assert nx["duration_us_live"] == pytest.approx(150.0) and nx["tested_candidates"] == 140_000_000
+    assert nx["equiv_gbs"] == pytest.approx(140e6 * 8 / 150e-6 / 1e9) and "never `frac`" in nx["label"]
+    assert nx["equiv_frac_of_hbm_peak"] == pytest.approx(nx["equiv_gbs"] / 8000.0) and r["frac"] < 0.01
+    assert r["by_kernel"][0]["kernel"].startswith("kp_rounds") and r["by_kernel"][0]["us_per_tick"] == 6000.0
+    # the team path: 32 passes as three launches with 9 000 lobbies by F o F, 78 as kt_fc with 2 700 by F, 23 inside kt_late
+    tpath = {"paths": 4, "crit_team_group": 0, "crit_team_passes": 133, "crit_team_f_passes": 32, "crit_team_fc_passes": 78,
+             "crit_team_late_passes": 23, "crit_team_f_lobbies": 9000, "crit_team_fc_lobbies": 2700, "crit_team_late_lobbies": 120,
+             "crit_team_lookups": 240, "crit_team_late_lookups": 40}
+    ms, parts = bench.team_critical_path_ms(tpath, boundary_us=1.6)
+    T = bench.TEAM_CRIT
+    assert parts["kt_f|kt_f2|kt_chase"] == pytest.approx((32 * 3 * 1.6 + 4500 * T["hop_pulled_us"]) * 1e-3)
+    assert parts["kt_fc"] == pytest.approx((78 * 1.6 + 2700 * T["hop_mem_us"]) * 1e-3)
+    assert parts["look-ups"] == pytest.approx((240 * 4 + 40 * 3) * T["trip_us"] * 1e-3) and ms == pytest.approx(sum(parts.values()))
+    r5 = bench.roofline_block("5v5", 4.5e7, 12, 8.3, 8.6, 1_000_000, 133, None, 1.6, None, None, tpath)
+    assert r5["critical_path_ms"] == pytest.approx(ms) and r5["frac_of_critical_path"] == pytest.approx(ms / 8.3)
+    assert r5["critical_path_model"]["passes"]["kt_fc"] == 78 and bench.team_critical_path_ms({"paths": 2}) == (None, None)
+
+
 def test_predict_speedup_is_the_slowest_rank_not_the_load_share():
     # BASELINE cfg-4 as measured on one GPU in round 2: the pool 66.8 ms, its 3M-player chain alone ~55 ms
     assert bench.predict_speedup(66.8, [55.0, 20.0, 0.0, 18.0]) == pytest.approx(66.8 / 55.0)
@@ -151,7 +191,11 @@ def test_bench_main_dry_run_prints_one_contract_line(monkeypatch, mode):
     assert d["degraded"] is False and d["path"]["paths"] == (2 if mode == "1v1" else 1) and d["path"]["host_looks"] >= 0
     lo, med, hi = d["ms_per_step_min_median_max"]
     assert lo <= med <= hi and lo <= d["ms_per_step"] * 1.0001 and d["n_gpus"] == d["rccl_ranks"] == 1
+    for k in ("by_kernel", "predicate_tests_physical", "critical_path_ms", "frac_of_critical_path"):     # round 6: always in the line
+        assert k in r, k
     if mode == "1v1":                                # 12000 players: every chain is kp_late's from its first pass
+        assert r["predicate_tests_physical"] > d["pairs_per_step"] * 0.5 and "predicate_tests_note" in r
+        assert "primitives_source" in r["critical_path_model"] and d["path"]["crit_team_group"] == 0xFFFFFFFF
         assert r["critical_path_ms"] > 0 and r["critical_path_model"]["passes"]["kp_rounds"] == 0
         assert r["critical_path_model"]["passes"]["kp_late"] == d["path"]["crit_passes"] == d["passes_max"]
     else:
@@ -296,3 +340,26 @@ def test_graft_entry_smoke_dry_run(monkeypatch, capsys):
     entry.smoke()
     out = capsys.readouterr().out
     assert out.count("smoke ok") == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_bench_two_ranks_on_one_device():
+    """`python bench.py --gpus 2 --same-device` on the box's one GPU (round 6): the N > 1 branch of the bench line with real
+    HIP engines in two processes — cfg-4's seeded 10M pool sharded by chain, gloo for the barriers and gathers (two RCCL
+    ranks cannot share a device), the union digest = the committed oracle digest.  Not a scaling number and the line says
+    so (`same_device`); what it proves is that the branch the driver runs on an 8-GPU node executes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--steps", "2", "--warmup", "1",
+                        "--no-secondary", "--no-stream"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["same_device"] is True and d["collective_backend"] == "gloo"
+    assert "10000000 players" in d["config"]["workload"]
+    sh = d["config"]["sharding"]
+    assert len(sh["per_rank"]) == 2 and sum(p_["players"] for p_ in sh["per_rank"]) == 10_000_000
+    assert d["exactness"]["ok"] is True and d["exactness"]["emission_digest"] == d["exactness"]["oracle_digest"]

@@ -63,6 +63,8 @@ def _case(kind, n):
     if kind == "5v5":
         return (make_config([mode_team(5, 2, 100, (1, 1, 1, 1, 1))], capacity=1 << 16),) + \
             make_pool(n, seed=6, role_weights=ROLE_WEIGHTS_5V5)
+    if kind == "cfg4":                                   # BASELINE cfg-4's shape at a fifth of its size: the chains go through the tiled rounds
+        return (make_config([mode_1v1(window=25, region_filter=True)], capacity=1 << 21),) + make_pool(n, seed=5)
     # two modes in one pool: 70 % 1v1 / 30 % 5v5 (BASELINE cfg-5's mix)
     cfg = make_config([mode_1v1(window=25, region_filter=True), mode_team(5, 2, 100, (1, 1, 1, 1, 1))],
                       capacity=1 << 16)
@@ -75,6 +77,9 @@ def _engine_cls(engine):
     if engine == "oracle":
         from oracle.oracle import OracleEngine
         return OracleEngine
+    if engine == "hip":                                  # the product library on cuda:0 (the gpu tier)
+        from microservice_matchmaking_amd import Engine
+        return Engine
     from emu_engine import EmuEngineSmall                # the product's kernel source under the CPU shim
     return EmuEngineSmall
 
@@ -163,7 +168,7 @@ def _stream_cfg():
                        capacity=1 << 16)
 
 
-def _stream_worker(rank, world, port, _unused, out_q):
+def _stream_worker(rank, world, port, engine, out_q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -171,7 +176,7 @@ def _stream_worker(rank, world, port, _unused, out_q):
     cfg = _stream_cfg()
     # the expected share of every chain is known up front: mode mix x the uniform rating groups
     w = np.outer([0.7, 0.3], [0.30, 0.10, 0.10, 0.10, 0.10, 0.10, 0.20])
-    with ShardedSearch(cfg, _engine_cls("oracle"), rank, world, w) as sh:
+    with ShardedSearch(cfg, _engine_cls(engine or "oracle"), rank, world, w) as sh:
         res = run_stream(sh, stream_schedule(**STREAM), mode_weights=(70, 30), role_weights=ROLE_WEIGHTS_5V5,
                          realtime=False)
         mine = {c: d for c, d in res["digests"].items() if sh.sharding.chain_owner[c] == rank}
@@ -202,3 +207,44 @@ def test_two_mode_stream_sharded_by_chain(oracle_cls, world):
     a = np.sort(np.concatenate([g[2] for g in gathered]))
     b = np.sort(np.concatenate(ref["floor"]))
     assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_two_ranks_two_real_engines_one_device(oracle_cls):
+    """Round 6: the N > 1 path with the REAL library.  Two processes, rendezvous over gloo, each a
+    ShardedSearch on a HIP engine — both on cuda:0, the only GPU of the box — a cfg-4-shaped 2M-player 1v1 pool split by
+    chain (application.ex:26-40: rating groups never interact): the union of the two ranks' emission lists is the single
+    oracle engine's, every player went to exactly one rank, the counters sum.  Until now the gloo tests ran the oracle or
+    the shim engine, so two ranks had never met libmm_engine.so.  (RCCL itself cannot put two ranks on one device: the
+    `nccl` branch of bench.py stays unexecuted until an N-GPU node runs it.)"""
+    n = 2_000_000
+    tot, gathered = _spawn(_worker, 2, (n, "cfg4", "hip"))
+    cfg, rating, cons = _case("cfg4", n)
+    with oracle_cls(cfg) as one:
+        one.enqueue(rating, cons)
+        ref = one.tick(0)
+    want = tick_digests(0, cfg.n_groups, ref.slots.astype(np.int64), ref.group)
+    assert tot == [len(ref), ref.stats["pairs"], ref.stats["pool_after"]]
+    got = {}
+    for digests, _, _ in gathered:
+        assert not (set(digests) & set(got))
+        got.update(digests)
+    assert union_digest(got) == union_digest(want)
+    assert sum(g[1] for g in gathered) == n and min(g[1] for g in gathered) > 0.3 * n
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_two_mode_stream_on_two_real_engines(oracle_cls):
+    """... and BASELINE cfg-5's two-mode stream over the same two ranks: 14 chains = (mode, group) on two HIP engines."""
+    gathered = _spawn(_stream_worker, 2, ("hip",))
+    cfg = _stream_cfg()
+    with ShardedSearch(cfg, oracle_cls, 0, 1) as one:
+        ref = run_stream(one, stream_schedule(**STREAM), mode_weights=(70, 30), role_weights=ROLE_WEIGHTS_5V5,
+                         realtime=False)
+    got = {}
+    for mine, _, _ in gathered:
+        got.update(mine)
+    assert union_digest(got) == union_digest(ref["digests"])
+    assert sum(g[1] for g in gathered) == ref["matched"] > 0

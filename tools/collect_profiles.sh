@@ -16,7 +16,7 @@ BENCH="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stream --n
 for MODE in 1v1 5v5; do
   [ "$WHAT" = both ] || [ "$WHAT" = "$MODE" ] || continue
   if [ $MODE = 1v1 ]; then FIRST=kp_init; KERNELS="kp_rounds kp_round kp_group kp_late kp_nx_init kp_init kp_finish"; PFX="kp_,kc_"; TJ=traffic_latest.json
-  else FIRST=kt_init; KERNELS="kt_build kt_fc kt_f kt_f2 kt_chase kt_emit kt_late"; PFX="kt_"; TJ=traffic_latest_5v5.json; fi
+  else FIRST=kt_init; KERNELS="kt_build kt_fc kt_f kt_f2 kt_chase kt_late"; PFX="kt_"; TJ=traffic_latest_5v5.json; fi
   rm -rf /tmp/prof_$MODE && rocprofv3 --kernel-trace -d /tmp/prof_$MODE -- $BENCH --mode $MODE > /dev/null 2> "$OUT/rocprof_$MODE.err"
   DB=$(find /tmp/prof_$MODE -name "*_results.db" | head -1)
   python "$R/tools/rocpd_stats.py" "$DB" > "$OUT/${TAG}_kernel_stats_1m_$MODE.csv"
@@ -27,7 +27,7 @@ for MODE in 1v1 5v5; do
     python "$R/tools/rocpd_pmc.py" "$DB" $C > "$OUT/${TAG}_pmc_$(echo $C | tr A-Z a-z)_1m_$MODE.csv" 2>> "$OUT/rocprof_$MODE.err"
   done
   # 4 timed + 1 warm-up tick were profiled
-  python "$R/tools/make_traffic.py" "$OUT/${TAG}_pmc_fetch_size_1m_$MODE.csv" "$OUT/${TAG}_pmc_write_size_1m_$MODE.csv" $MODE 1000000 5 "$PFX" > "$OUT/$TJ"
+  python "$R/tools/make_traffic.py" "$OUT/${TAG}_pmc_fetch_size_1m_$MODE.csv" "$OUT/${TAG}_pmc_write_size_1m_$MODE.csv" $MODE 1000000 5 "$PFX" "$OUT/${TAG}_kernel_stats_1m_$MODE.csv" > "$OUT/$TJ"
   cp "$OUT/$TJ" "$R/profiles/$TJ"
   python "$R/bench.py" --mode $MODE --steps 20 --warmup 5 > "$OUT/${TAG}_bench_1m_$MODE.json" 2> "$OUT/bench_$MODE.err"
   tail -c 600 "$OUT/${TAG}_kernel_passes_1m_$MODE.txt"; head -6 "$OUT/${TAG}_kernel_stats_1m_$MODE.csv"

@@ -2,8 +2,10 @@
 """profiles/traffic_latest*.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of
 `bench.py`: sums the walk's kernels per tick and applies the gfx950 corrections of
 MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request: read side doubled; both in KB).
-Usage: python tools/make_traffic.py <fetch.csv> <write.csv> <mode> <players> <ticks> <kernel prefixes, comma separated> > out.json
-The CSVs are the output of tools/rocpd_pmc.py (kernel,counter,dispatches,sum)."""
+Usage: python tools/make_traffic.py <fetch.csv> <write.csv> <mode> <players> <ticks> <kernel prefixes, comma separated> [kernel stats csv] > out.json
+The CSVs are the output of tools/rocpd_pmc.py (kernel,counter,dispatches,sum); the optional seventh argument is the
+--kernel-trace summary of the same command (tools/rocpd_stats.py: kernel,calls,total_ns,...), from which the file also
+carries every walk kernel's duration per tick (bench.py's roofline.by_kernel; round 6)."""
 import csv
 import json
 import os
@@ -22,7 +24,17 @@ def load(path, prefixes):
     return out
 
 
-def main(fetch_csv, write_csv, mode, players, ticks, prefixes):
+def load_stats(path, prefixes, ticks):
+    out = {}
+    for row in csv.DictReader(open(path)):
+        k = row["kernel"].replace("void ", "")
+        if any(k.startswith(p) for p in prefixes):
+            out[k] = {"us_per_tick": float(row["total_ns"]) / ticks / 1e3, "calls_per_tick": int(row["calls"]) / ticks,
+                      "avg_us": float(row["avg_ns"]) / 1e3}
+    return out
+
+
+def main(fetch_csv, write_csv, mode, players, ticks, prefixes, stats_csv=None):
     ticks = float(ticks)
     prefixes = prefixes.split(",")
     f, w = load(fetch_csv, prefixes), load(write_csv, prefixes)
@@ -40,9 +52,10 @@ def main(fetch_csv, write_csv, mode, players, ticks, prefixes):
                       "section HBM); WRITE_SIZE uncalibrated, taken as is; both x1024 (KB)",
         "walk_hbm_bytes_per_tick": (2.0 * fetch + write) * 1024.0,
         "per_kernel_kb_per_tick": per,
+        "per_kernel_time": load_stats(stats_csv, prefixes, ticks) if stats_csv else None,
         "note": "Infinity-Cache hits are counted by these counters; the working set of a 1M-player pool is cache resident",
     }, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:7])
+    main(*sys.argv[1:8])
