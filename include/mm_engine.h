@@ -220,8 +220,6 @@ typedef struct mm_tuning {
     uint32_t team_late;         /* lobbies per pass at or under which kt_late takes over (0: never)   MM_TEAM_LATE       [6]  */
     uint32_t team_late0;        /* arrivals since a mode's last tick at or under which kt_late walks the tick from its first pass (0: never) MM_TEAM_LATE0 [512] */
     uint32_t team_cap;          /* sub-queue entries one thread of kt_f looks at per role, 1..4096    MM_TEAM_CAP        [512] */
-    /* (appended) */
-    uint32_t pair_xtiles;       /* tiles of the longest chain a kp_rounds batch over SEVERAL XCDs may have, 0..256 (<= pair_ptiles: never) MM_PAIR_XTILES [256] */
 } mm_tuning;
 
 /* Fills *t (t->size = the caller's sizeof on entry) with the defaults: the built-in values in [brackets] above, each
@@ -408,8 +406,6 @@ typedef struct mm_path_stats {
     uint32_t crit_team_late_lobbies;/* ... by its own look at the anchor's record inside kt_late                           */
     uint32_t crit_team_lookups;    /* look-ups the chaser did itself in the pass kernels (stored lobby's fill, the lobby a pass ends on, anchors without F) */
     uint32_t crit_team_late_lookups;/* ... inside kt_late                                                                  */
-    uint32_t pair_rounds_x_launches;/* kp_rounds launches of that tick whose chains sat on several XCDs (agent-scope fences at the barrier) */
-    uint32_t pair_rounds_x_ghops;  /* ... hops over a whole group of eight tiles the first tiles' walkers took in them (the second route level composed inside the launch) */
 } mm_path_stats;
 int mm_path_stats_get(mm_engine* e, mm_path_stats* out);
 

@@ -87,8 +87,7 @@ class MMPathStats(C.Structure):
         "crit_timed_passes", "crit_timed_hops", "crit_barrier_cycles", "crit_hop_cycles", "clk_cycles", "clk_wall_ticks",
         "pair_nx_init_ns", "pair_tested_lo", "pair_tested_hi", "pair_tested_nx_lo", "pair_tested_nx_hi",
         "crit_team_group", "crit_team_passes", "crit_team_f_passes", "crit_team_fc_passes", "crit_team_late_passes",
-        "crit_team_f_lobbies", "crit_team_fc_lobbies", "crit_team_late_lobbies", "crit_team_lookups", "crit_team_late_lookups",
-        "pair_rounds_x_launches", "pair_rounds_x_ghops")]
+        "crit_team_f_lobbies", "crit_team_fc_lobbies", "crit_team_late_lobbies", "crit_team_lookups", "crit_team_late_lookups")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "size"}

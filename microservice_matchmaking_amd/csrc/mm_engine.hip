@@ -990,7 +990,6 @@ struct mm_engine {
     uint32_t* d_pk_headp[2];
     bool pair_persist;         // MM_PAIR_PERSIST=0: never several passes per launch (kp_rounds); one launch per pass as before (A/B)
     uint32_t pair_ptiles;      // MM_PAIR_PTILES: tiles of the longest chain a kp_rounds batch may have (one workgroup per CU of ONE XCD: 32)
-    uint32_t pair_xtiles;      // MM_PAIR_XTILES: ... a kp_rounds batch over several XCDs may have (a workgroup per CU of the chip; <= pair_ptiles: never)
     uint32_t pair_pcool;       // batches for which kp_rounds stays off after a launch that gave up (a time-out: somebody else holds the CUs)
     uint32_t pair_pstops;      // launches that gave up so far (diagnostics)
     uint32_t pair_pinject;     // MM_PAIR_PINJECT: PairParams.pinject (tests)
@@ -1404,7 +1403,6 @@ static const TuneDesc k_tune[] = {
     MM_TD(team_late, "MM_TEAM_LATE", 6u, 0u, 0xFFFFFFFFu, 0u),
     MM_TD(team_late0, "MM_TEAM_LATE0", 512u, 0u, 0xFFFFFFFFu, 0u),
     MM_TD(team_cap, "MM_TEAM_CAP", TT_SCAN_CAP, 1u, 4096u, 0u),
-    MM_TD(pair_xtiles, "MM_PAIR_XTILES", 256u, 0u, 256u, 0u),
 };
 #undef MM_TD
 static const uint32_t k_tune_n = (uint32_t)(sizeof(k_tune) / sizeof(k_tune[0]));
@@ -1529,7 +1527,6 @@ extern "C" int mm_engine_create_ex(const mm_config* cfg, const mm_tuning* tuning
             e->round_ctr = 0;
             e->pair_persist = t.pair_persist != 0u;
             e->pair_ptiles = t.pair_ptiles;
-            e->pair_xtiles = t.pair_xtiles;
             e->pair_pinject = t.pair_pinject;
             // the first barrier of a launch is where a workgroup that found no CU is waited for (another engine's launch in the
             // way ends within a millisecond or two); behind it everybody is on the chip and only slow, never absent
@@ -2390,39 +2387,17 @@ static int pair_walk(mm_engine* e, uint32_t mode, const ModeDev& M, bool purge)
                 P.xslots = 0;
                 uint32_t tof[MM_MAX_GROUPS];
                 for (uint32_t g = 0; g < G; ++g) tof[g] = P.bm[g] ? (P.bm[g] + tp - 1u) / tp : 0u;
-                // (round 6) ... or, for chains of pair_ptiles + 1 .. pair_xtiles tiles of the longest length, over SEVERAL XCDs: the
-                // same kernel with agent-scope fences at its barrier (kp_rounds<.., 1>), a workgroup per CU of the whole chip
-                bool persist_x = !persist && e->pair_persist && !compact && tp == PK_TMAX &&
-                                 e->pair_xtiles > e->pair_ptiles && tiles > e->pair_ptiles && tiles <= e->pair_xtiles;
-                if (persist_x && e->pair_pcool) { --e->pair_pcool; persist_x = false; e->ps.degraded = 1; }
-                if (persist || persist_x) {
+                if (persist) {
                     // every chain's workgroups on ONE XCD, a CU each: they talk through that XCD's L2 and must all be on the chip
-                    // (persist_x: a chain on as many XCDs as its tiles need, still a CU each: the map refuses more than 32 a XCD)
-                    const uint32_t slots = pair_xcd_map(P, tof, G, !persist_x);
+                    const uint32_t slots = pair_xcd_map(P, tof, G, true);
                     if (slots) {
+                        P.grp = 0;
                         // (the arrival words are zero: kp_init at the start of the tick, kc_commit behind every batch)
                         // (the batch ends by itself when the longest chain can be compacted into shorter tiles: it may be long)
                         const uint32_t K = e->pair_pbatch, slice = MM_PERSIST_SLICE ? MM_PERSIST_SLICE : K + 1u;
-                        // the second route level inside the launch (mm_pair.inc, compose_group): from pair_group_min tiles, as kp_round's
-                        const bool xgroup = persist_x && e->pair_group_min && tiles >= e->pair_group_min;
-                        P.grp = xgroup ? PK_GS : 0u;
-                        P.gphase = (xgroup && MM_PERSIST_SLICE) ? 1u : 0u;
-                        P.gstamp = e->round_ctr;                         // the entries' stamps: this launch's own (grec outlives it)
-                        if (xgroup) e->round_ctr += K + 2u;
-                        for (uint32_t it = 0; it <= K; it += slice) {
-                            const uint32_t ie = it + slice < K + 1u ? it + slice : K + 1u;
-                            if (persist_x) {
-                                hipLaunchKernelGGL((kp_rounds<PK_TMAX, 1>), dim3(8u * slots), dim3(PT_THREADS), 0, e->stream, P, it, ie, K);
-                                if (P.gphase) {                          // (the CPU shim: an iteration's composition as a launch of its own)
-                                    P.gphase = 2u;
-                                    hipLaunchKernelGGL((kp_rounds<PK_TMAX, 1>), dim3(8u * slots), dim3(PT_THREADS), 0, e->stream, P, it, ie, K);
-                                    P.gphase = 1u;
-                                }
-                            } else TILE_LAUNCH(kp_rounds, dim3(8u * slots), dim3(PT_THREADS), P, it, ie, K);
-                        }
-                        P.grp = 0; P.gphase = 0;
+                        for (uint32_t it = 0; it <= K; it += slice)
+                            TILE_LAUNCH(kp_rounds, dim3(8u * slots), dim3(PT_THREADS), P, it, it + slice < K + 1u ? it + slice : K + 1u, K);
                         ++e->ps.pair_rounds_launches;
-                        if (persist_x) ++e->ps.pair_rounds_x_launches;
                         after_persist = true;
                         COMPACT_LAUNCH();
                         HIPCHK(e, hipGetLastError());
@@ -2992,7 +2967,6 @@ static int tick_impl(mm_engine* e, uint32_t mode, uint32_t* n_matches, mm_stats*
         // the primitives of its serial chain as tile 1's walker timed them (PairChain.ptm), the clock (kp_late's chase in
         // shader-clock cycles and in 100 MHz ticks), kp_nx_init by HIP events, the physical predicate tests (pair_tune bit 13)
         const PairChain& pc = e->h_pchains[gc];
-        for (uint32_t g = 0; g < G; ++g) if (e->h_pchains[g].fast) e->ps.pair_rounds_x_ghops += e->h_pchains[g].xghops;
         if (e->ps.crit_group != 0xFFFFFFFFu) {
             e->ps.crit_timed_passes = pc.ptm[5];
             e->ps.crit_timed_hops = pc.ptm[15];

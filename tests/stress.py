@@ -48,7 +48,7 @@ PAIR_KNOBS = {
     "pair_persist": [0, 1], "pair_ptiles": [3, 5, 6, 8, 12, 20, 32], "pair_pbatch": [1, 2, 7, 48, 96],
     "pair_batch": [1, 2, 7, 48], "pair_ptimeout_us": [0, 50, 5000], "pair_pinject": [0] + list(range(1, 41)),
     "pair_tiles_max": [10, 20, 40], "pair_tile_fixed": [0, 1], "pair_xcd": [0, 1], "pair_group_min": [0, 4, 64],
-    "pair_nxseg": [0, 64, 256, 1024, 2048], "pair_nxstage": [0, 512, 2048], "pair_xtiles": [0, 16, 40, 64, 256],
+    "pair_nxseg": [0, 64, 256, 1024, 2048], "pair_nxstage": [0, 512, 2048],
 }
 TEAM_KNOBS = {
     "team_batch": [1, 2, 4, 16], "team_f2": [0, 1, 3, 32, 1000], "team_rebuild": [1, 3, 8, 32], "team_emit_max": [1, 2, 8, 32],

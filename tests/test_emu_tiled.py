@@ -174,42 +174,6 @@ def test_path_stats_say_which_launch_shapes_a_tick_took(oracle_cls, monkeypatch,
         assert ps["crit_rounds_passes"] == 0 and ps["pair_round_launches"] > 0
 
 
-@pytest.mark.parametrize("tuning", [{"pair_ptiles": 4, "pair_xtiles": 16}, {"pair_ptiles": 3, "pair_xtiles": 12, "pair_pbatch": 3},
-                                    {"pair_ptiles": 4, "pair_xtiles": 16, "pair_pinject": 2}, {"pair_ptiles": 2, "pair_xtiles": 6},
-                                    {"pair_ptiles": 4, "pair_xtiles": 16, "pair_group_min": 0}, {"pair_ptiles": 1, "pair_xtiles": 256, "pair_group_min": 2}],
-                         ids=["4..16 tiles", "3..12 tiles, batches of 3", "a stop in the second pass", "2..6 tiles", "one route level",
-                              "2..256 tiles, groups from 2"])
-def test_chains_too_long_for_one_xcd_take_kp_rounds_over_several(oracle_cls, tuning):
-    """Round 6: kp_rounds<.., 1> — the batch-of-passes launch for chains of pair_ptiles + 1 .. pair_xtiles tiles, their
-    workgroups on several XCDs with agent-scope fences at the flag barrier (mm_pair.inc).  The shim has no caches to fence;
-    what it tests is the host's hand-overs (kp_round while the chain is longer than pair_xtiles tiles, the multi-XCD batches,
-    the yield into the one-XCD batches when the chain's queued players fit pair_ptiles tiles, a stop of the test hook and its
-    cool-down) and the kernel's control flow without the PF_XCD check — ticks equal to the oracle's, with arrivals."""
-    cfg = make_config([mode_1v1(window=30, region_filter=True)], capacity=16384)
-    rng = np.random.default_rng(41)
-    with EmuEngineSmall(cfg, tuning) as a, oracle_cls(cfg) as b:
-        x_launches = g_hops = 0
-        for k, n in enumerate((7000, 2500)):
-            rating = rng.integers(0, 1401 if k == 0 else 5001, size=n).astype(np.int32)     # tick 0: one chain of fourteen tiles
-            cons = cons_make(0, rng.integers(0, 2, size=n), 0, 0)
-            assert np.array_equal(a.enqueue(rating, cons), b.enqueue(rating, cons))
-            assert_same_tick(a.tick(0), b.tick(0), "multi-XCD batches, tick %d" % k)
-            assert_same_state(a, b, cfg, "multi-XCD batches, tick %d" % k)
-            ps = a.path_stats()
-            x_launches += ps["pair_rounds_x_launches"]
-            g_hops += ps["pair_rounds_x_ghops"]
-            assert ps["pair_rounds_x_launches"] <= ps["pair_rounds_launches"]
-            if tuning.get("pair_pinject") and k == 0:
-                assert ps["pair_stops_inject"] >= 1 and ps["degraded"] == 1
-        assert x_launches >= 1
-        # the second route level (groups of PK_GS = 4 tiles in this build, from pair_group_min = 5 tiles): composed INSIDE the launch
-        # by the first tiles' workgroups, taken by the walkers of the tiles outside the group
-        if tuning.get("pair_group_min", 5) == 0:
-            assert g_hops == 0
-        elif tuning["pair_xtiles"] >= 16 and not tuning.get("pair_pinject"):
-            assert g_hops > 0
-
-
 @pytest.mark.parametrize("seed", [18, 21, 39])
 def test_the_tile_length_of_a_tick_never_grows(oracle_cls, monkeypatch, seed):
     """Two chains of similar length, sparse fits, kp_rounds limited to four tiles (MM_PAIR_PTILES=4).  Both start too long
@@ -223,7 +187,6 @@ def test_the_tile_length_of_a_tick_never_grows(oracle_cls, monkeypatch, seed):
     One cap for both kinds of batch now, and a guard that compacts every tiled chain should a tile length grow all the
     same.  These three seeds differed from the oracle on round 4's build of this geometry."""
     monkeypatch.setenv("MM_PAIR_PTILES", "4")
-    monkeypatch.setenv("MM_PAIR_XTILES", "0")          # (round 6: no multi-XCD batches for the chains of 5+ tiles — this scenario is about kp_round's)
     rng = np.random.default_rng(seed)
     ra, rb = rng.integers(4000, 5001, size=2560), rng.integers(0, 1500, size=2500)
     rating = np.concatenate([ra, rb]).astype(np.int32)
