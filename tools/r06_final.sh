@@ -21,7 +21,7 @@ python bench.py --players 10000000 --mode 5v5 --steps 3 --warmup 1 --no-cpu-base
 python bench.py --dist normal --steps 10 --warmup 3 --no-cpu-baseline --no-stream --no-secondary --no-pcie --no-cfg3 --no-prediction > $OUT/${T}_bench_1m_1v1_normal.json 2> $OUT/bench_normal.err
 python bench.py --dist normal --mode 5v5 --steps 8 --warmup 2 --no-cpu-baseline --no-stream --no-secondary --no-pcie --no-cfg3 --no-prediction > $OUT/${T}_bench_1m_5v5_normal.json 2> $OUT/bench_normal5.err
 ( cd /tmp && for M in 1v1 5v5; do rm -rf /tmp/qg_$M; timeout 200 rocprofv3 --kernel-trace -d /tmp/qg_$M -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stream --no-secondary --no-boundary --no-pcie --no-prediction --mode $M > /dev/null 2> /tmp/qg_$M.err; DB=$(find /tmp/qg_$M -name "*_results.db" | head -1); if [ $M = 1v1 ]; then F=kp_init; else F=kt_init; fi; python $R/tools/rocpd_gaps.py $DB $F 6 > $OUT/${T}_timeline_gaps_1m_$M.txt 2>&1; done )
-( cd /tmp && rm -rf /tmp/prof_h && rocprofv3 --kernel-trace -d /tmp/prof_h -- python $R/tools/heaviest_chain_tick.py 10000000 2 2> $OUT/heaviest.err > $OUT/${T}_heaviest_chain_10m.txt; DB=$(find /tmp/prof_h -name "*_results.db" | head -1); python $R/tools/rocpd_passes.py $DB kp_init kp_rounds kp_round kp_late kp_nx_init kc_scatter >> $OUT/${T}_heaviest_chain_10m.txt )
+( cd /tmp && rm -rf /tmp/prof_h && rocprofv3 --kernel-trace -d /tmp/prof_h -- python $R/tools/heaviest_chain_tick.py 10000000 2 2> $OUT/heaviest.err > $OUT/${T}_heaviest_chain_10m.txt; DB=$(find /tmp/prof_h -name "*_results.db" | head -1); python $R/tools/rocpd_passes.py $DB kp_init kp_rounds kp_round kp_group kp_late kp_nx_init kc_scatter >> $OUT/${T}_heaviest_chain_10m.txt )
 MM_PAIR_DEBUG=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-stream --no-secondary 2>&1 > /dev/null | grep -E "kp_rounds:|tile1 cycles|g0 fast" | tail -16 > $OUT/${T}_pair_phase_timers.txt
 MM_PAIR_DEBUG=1 timeout 120 python bench.py --mode 5v5 --steps 3 --warmup 1 --no-cpu-baseline --no-stream --no-secondary --no-pcie --no-prediction 2>&1 > /dev/null | grep "mm-team" | tail -14 | grep -v chaser > $OUT/${T}_team_phase_timers.txt
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/${T}_pytest_gpu.log 2>&1
