@@ -308,6 +308,9 @@ def parse():
     ap.add_argument("--stream-qps", type=int, default=100_000)
     ap.add_argument("--stream-seconds", type=float, default=3.0)
     ap.add_argument("--stream-tick-ms", type=float, default=10.0)
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the extra untimed tick that counts the physical predicate tests (tools/collect_profiles.sh: "
+                         "a profile divided by its ticks must hold the timed engine's ticks only)")
     ap.add_argument("--same-device", action="store_true",
                     help="N > 1 ranks that all use GPU 0 and meet over gloo instead of RCCL (two RCCL ranks cannot share a device): "
                          "what a 1-GPU box can run of the N > 1 branch — real HIP engines in N processes, the sharding, the "
@@ -692,7 +695,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.same_device:
-            dist.init_process_group("gloo")
+            # (gloo announces its connections on the C-level stdout: the one JSON line must stay alone there)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
             ones = torch.ones(1)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -1067,7 +1078,7 @@ def main():
         boundary_us = None if args.no_boundary else measure_boundary_us(torch)
         a = main_roofline_args
         probe = None
-        if world == 1 and args.mode == "1v1":
+        if world == 1 and args.mode == "1v1" and not args.no_probe:
             # the predicate tests the pair kernels PHYSICALLY perform in one tick of the headline pool: a second engine whose
             # mm_tuning has pair_tune bit 13 (the counters are atomics — never on the timed engine), one untimed step
             rating_p, cons_p = pool_of(wl, n)

@@ -355,8 +355,8 @@ def test_gpu_bench_two_ranks_on_one_device():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--steps", "2", "--warmup", "1",
                         "--no-secondary", "--no-stream"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                   # ONE line on stdout, nothing else (gloo's own chatter goes to stderr)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["same_device"] is True and d["collective_backend"] == "gloo"
     assert "10000000 players" in d["config"]["workload"]

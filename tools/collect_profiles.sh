@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stream --no-secondary --no-boundary"
+BENCH="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stream --no-secondary --no-boundary --no-probe"
 for MODE in 1v1 5v5; do
   [ "$WHAT" = both ] || [ "$WHAT" = "$MODE" ] || continue
   if [ $MODE = 1v1 ]; then FIRST=kp_init; KERNELS="kp_rounds kp_round kp_group kp_late kp_nx_init kp_init kp_finish"; PFX="kp_,kc_"; TJ=traffic_latest.json
