@@ -308,6 +308,10 @@ def parse():
     ap.add_argument("--stream-qps", type=int, default=100_000)
     ap.add_argument("--stream-seconds", type=float, default=3.0)
     ap.add_argument("--stream-tick-ms", type=float, default=10.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 with the process group all the same: RCCL (`nccl`) is initialised on the one GPU and the barrier, the "
+                         "all-reduce on the device and the gathers of the N > 1 branch run for real, on one rank — what a 1-GPU box can "
+                         "execute of that branch with the backend the driver's 8-GPU run uses")
     ap.add_argument("--no-probe", action="store_true",
                     help="skip the extra untimed tick that counts the physical predicate tests (tools/collect_profiles.sh: "
                          "a profile divided by its ticks must hold the timed engine's ticks only)")
@@ -691,19 +695,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     rccl_ranks = 1
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                              # --force-dist without a launcher: a rendezvous of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.same_device:
-            # (gloo announces its connections on the C-level stdout: the one JSON line must stay alone there)
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group("gloo")
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
+            dist.init_process_group("gloo")
             ones = torch.ones(1)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -874,7 +877,7 @@ def main():
             "unit": "matched players/s",
             "n_gpus": world,
             "rccl_ranks": rccl_ranks,
-            "collective_backend": "none" if world == 1 else ("gloo" if args.same_device else "nccl (RCCL)"),
+            "collective_backend": "none" if dist is None else ("gloo" if args.same_device else "nccl (RCCL)"),
             "same_device": bool(args.same_device and world > 1),
             "launched_by": "bench.py itself (--gpus N without a launcher)" if os.environ.get("MM_BENCH_LAUNCHED") else
                            ("torch.distributed.run / env" if world > 1 else "single process"),
@@ -1103,4 +1106,13 @@ def main():
 
 
 if __name__ == "__main__":
+    # The process's stdout (file descriptor 1) belongs to the ONE JSON line.  Libraries print there too — RCCL its banner
+    # ("Hostname : ...", "Librccl path : ...") when the `nccl` process group of the N > 1 branch comes up, gloo its connection
+    # report — and the driver reads stdout: descriptor 1 goes to stderr for the whole run, the line is written to a copy of
+    # the original.  (Found in round 6 by running the RCCL branch for the first time, on one rank: `--force-dist`.)
+    sys.stdout.flush()
+    _line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = _line_out
     main()
+    _line_out.flush()

@@ -363,3 +363,23 @@ def test_gpu_bench_two_ranks_on_one_device():
     sh = d["config"]["sharding"]
     assert len(sh["per_rank"]) == 2 and sum(p_["players"] for p_ in sh["per_rank"]) == 10_000_000
     assert d["exactness"]["ok"] is True and d["exactness"]["emission_digest"] == d["exactness"]["oracle_digest"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_bench_rccl_branch_on_one_rank():
+    """`python bench.py --force-dist` (round 6): the process group of the N > 1 branch with the backend the driver's 8-GPU run
+    uses — `nccl` = RCCL — initialised on the box's one GPU, world size 1: communicator creation, the all-reduce of ones on
+    the device, every barrier of the timed region and the gathers run for real.  What it cannot show is a second rank:
+    no multi-GPU node was available to any round."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1",
+                        "--no-secondary", "--no-stream", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["collective_backend"] == "nccl (RCCL)" and d["same_device"] is False
+    assert d["exactness"]["ok"] is True and d["value"] > 5e7
