@@ -24,8 +24,9 @@ Secondary keys, never `value`: `weak_scaling` (every rank its own 1M pool) and `
 (BASELINE configs[4]: the 100k players/s 70/30 stream, chains sharded over the ranks).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the walk (the search proper: for a 1v1
-mode the pair path's kernel sequence kp_nx_init, kp_round x rounds (one launch per pass of the
-cursor), kp_late, kp_finish — DESIGN.md §4; for team modes kt_build/kt_f/kt_chase/kt_emit per pass):
+mode the pair path's kernel sequence kp_nx_init, kp_round / kp_rounds (one launch per pass of the cursor / a batch
+of passes per launch), kp_late, kp_finish — DESIGN.md §4; for team modes kt_build, kt_f | kt_f2 | kt_chase or one
+kt_fc launch per pass, kt_late):
 achieved = algorithmic bytes / HIP-event time of that sequence on the engine's stream,
 algorithmic bytes = pair evaluations of the reference algorithm (the oracle's count, which
 the engine reproduces bit-exactly) x 8 B (rating + cons of the candidate).
