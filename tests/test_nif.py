@@ -141,6 +141,7 @@ def test_gpu_backend_behind_the_same_nif():
     """The same shim over libmm_engine.so on the MI355X: 40k players, both modes, cancels."""
     hip = Beam("hip")
     scenario(hip, n=40000, seed=9)
+    scenario(hip, n=40000, seed=10, tuning={"pair_pbatch": 7, "pair_ptiles": 3, "team_late": 0, "team_f2": 2})    # create/3: its own mm_tuning
     hip.gc()
     assert hip.live_resources() == 0
 
