@@ -224,3 +224,21 @@ def test_matches_ranges_over_the_per_group_regions(oracle_cls):
         assert e._fn("matches")(e._h, n, 1, None, None, None, None) == -8
         assert e._fn("matches")(e._h, 0, n + 1, None, None, None, None) == -8
         assert e._fn("matches")(e._h, n, 0, None, None, None, None) == 0
+
+
+@pytest.mark.parametrize("what", ["pair", "team"])
+def test_shim_randomised_stress_with_fuzzed_knobs(what, monkeypatch, capsys):
+    """tests/stress.py --fuzz-knobs on the fiber-shim build (tiny geometry), twenty-five seconds each: every scenario's
+    engine gets a random COMBINATION of mm_tuning fields through mm_engine_create_ex and every tick equals the oracle's.
+    The CPU tier's share of round 6's lesson (the device's: test_gpu_randomised_stress_with_fuzzed_knobs; the soak:
+    profiles/r06_stress_fuzz_knobs.txt)."""
+    import importlib.util
+    import os
+    monkeypatch.setenv("MM_STRESS_ENGINE", "emu_small")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress.py")
+    spec = importlib.util.spec_from_file_location("shim_stress_fuzz_" + what, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["25", "11" if what == "pair" else "12"] + (["team"] if what == "team" else []) + ["--fuzz-knobs"])
+    out = capsys.readouterr().out
+    assert "--fuzz-knobs" in out and "scenarios ok" in out, out
