@@ -103,6 +103,25 @@ def test_tuning_record_by_name_and_by_layout(lib, monkeypatch):
     assert Engine.tuning_record({"team_late": 3})[1 + names.index("team_late")] == 3
 
 
+def test_every_tuning_field_round_trips_through_set_by_name(lib):
+    """mm_tuning_set writes exactly the named word of the record and nothing else, for every field the library lists, at
+    both ends of what it accepts (the defaults are always acceptable: a record of defaults set field by field is itself)."""
+    from microservice_matchmaking_amd import Engine
+    Engine._lib = lib
+    names, base = Engine.tuning_names(), Engine.tuning_record()
+    for i, n in enumerate(names):
+        rec = Engine.tuning_record({n: base[1 + i]})
+        assert list(rec) == list(base), n
+        for v in (0, 1, 2, 64, 0xFFFFFFFF):
+            try:
+                rec = Engine.tuning_record({n: v})
+            except MMError as ex:
+                assert ex.status == -8, (n, v)          # MM_ERR_RANGE, never anything else for a known name
+                continue
+            diff = [k for k in range(len(rec)) if rec[k] != base[k]]
+            assert diff in ([], [1 + i]) and rec[1 + i] == v, (n, v)
+
+
 def test_library_level_calls_need_no_gpu(lib):
     assert lib.mm_abi_version() == 1
     assert lib.mm_strerror(0) == b"ok"

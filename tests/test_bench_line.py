@@ -320,6 +320,21 @@ def test_bench_gpus_n_as_one_command_starts_its_own_ranks():
     assert len(d["config"]["sharding"]["per_rank"]) == 2 and d["exactness"]["ok"] is True
 
 
+def test_bench_force_dist_runs_the_collective_branch_on_one_rank():
+    """`--force-dist` (round 6): N = 1 with the process group up — the barriers, the all-reduce of ones and the gathers of the
+    N > 1 branch execute on one rank (here over gloo and the shim engine; on the device over RCCL:
+    test_gpu_bench_rccl_branch_on_one_rank, which is what found RCCL's banner on stdout)."""
+    import subprocess
+    cmd, env = _dry_cmd("--force-dist", "--players", "12000", "--steps", "2", "--warmup", "1", "--no-secondary", "--no-stream",
+                        "--no-cpu-baseline")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["collective_backend"] != "none" and d["exactness"]["ok"] is True
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     """WORLD_SIZE set by a launcher and different from --gpus: non-zero exit, no line."""
     import subprocess
